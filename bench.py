@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the MI355X-native llama2_q4 on Llama-2-7B-geometry AWQ int4 g128 weights.
+
+Contract (one JSON line on rank 0):
+  step     = one full greedy `-n 256` generation (8-token prompt fed one token per step + 247 generated tokens =
+             255 timed tokens, the reference's own rule (pos-1)/elapsed, llama2_q4.cu:485-489), weights resident
+             in HBM before the timed region.
+  value    = total timed tokens of all ranks / max-over-ranks wall time of K steps  (whole-job tokens/s).
+  N > 1    = N independent replicas (the token loop is sequential, SURVEY 8e: replicas only, no data-path
+             collective); torch.distributed is used for the barrier and the max-over-ranks only.
+  roofline = the decode path's dominant kernel (fused rmsnorm + gate/up int4 GEMV + SiLU): algorithmic bytes per
+             launch / its average launch duration, measured here with dispatch timestamps over a ring of the 32
+             layers' weights (1.5 GB > the 256 MiB Infinity Cache), against the 8 TB/s HBM3E peak.
+  cpu_baseline = the CPU restatement (oracle/, "port") of run_llama_network timed on the host cores for a few
+             decode steps of the SAME checkpoint; it is a reported baseline, not the target.
+Synthetic weights: no network, no real checkpoint -- llama_cu_awq_amd/synth.py, seed 20240229.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PROMPT_IDS = [1, 2436, 385, 3686, 388, 1048, 22796, 118]   # encode("write an essay about GPUs", bos=1), reference tokenizer
+HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PUBLISHED_TOKS = 200.787402                                 # README.md:111, RTX 4090
+
+
+def qweight_bytes(K, N):
+    pwh = (K + 31) // 32 * 4
+    sh = (K + 127) // 128
+    pzh = (sh + 7) // 8
+    return pwh * N * 4 + pzh * N * 4 + sh * N * 2
+
+
+def kernel_bytes(cfg):
+    """Algorithmic bytes per launch of each timed kernel (weights + metadata + vectors in/out)."""
+    d, h, v = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+    return {
+        0: ("ffn_rmsnorm_gate_up_silu_q4", 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2),
+        1: ("gemv_q4_dim_to_hidden", qweight_bytes(d, h) + d * 2 + h * 2),
+        2: ("gemv_q4_hidden_to_dim_accum", qweight_bytes(h, d) + h * 2 + 2 * d * 2),
+        3: ("qkv_rmsnorm_rope_q4", 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2),
+        4: ("gemv_q4_oproj_accum", qweight_bytes(d, d) + d * 2 + 2 * d * 2),
+        5: ("classifier_f16", v * d * 2 + d * 2 + v * 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="7b", help="geometry name in llama_cu_awq_amd.synth.GEOMETRIES")
+    ap.add_argument("--ntok", type=int, default=256, help="the CLI's -n")
+    ap.add_argument("--model-dir", default=os.environ.get("Q4_MODEL_DIR", "/tmp"))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--force-dist", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or args.force_dist
+
+    from llama_cu_awq_amd import api, synth   # raises if libllama2_q4.so is missing: no fallback
+    L = api.lib()
+    api.check(L.q4_set_device(local_rank if world > 1 else 0))
+
+    dist = None
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        sync_t = torch.zeros(1, device="cuda")
+
+    def barrier():
+        api.check(L.q4_device_synchronize())
+        if use_dist:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- synthetic checkpoint (rank 0 writes, everyone loads) --------------------------------------
+    geom = synth.GEOMETRIES[args.model]
+    path = os.path.join(args.model_dir, "llama2_q4_synth_%s_seed20240229.bin" % args.model)
+    t_gen = 0.0
+    if rank == 0 and not (os.path.exists(path) and os.path.getsize(path) == synth.model_bytes(geom)):
+        t0 = time.time()
+        synth.write_model(path, geom)
+        t_gen = time.time() - t0
+    if use_dist:
+        dist.barrier()
+    else:
+        while not os.path.exists(path):
+            time.sleep(0.5)
+
+    stream = C.c_void_p()
+    api.check(L.q4_stream_create(C.byref(stream)))
+    L.q4_set_stream(stream)
+    t0 = time.time()
+    tr = api.Transformer(path, temperature=0.0)
+    t_load = time.time() - t0
+    cfg = tr.config
+    ntok = min(args.ntok, cfg.seq_len)
+
+    # ---- warmup (also captures the graphs), then K timed generations -------------------------------
+    tokens0 = None
+    for _ in range(max(args.warmup, 0)):
+        tokens0, _, _, _ = tr.generate_ids(PROMPT_IDS, ntok)
+    barrier()
+    t0 = time.perf_counter()
+    timed_tokens = 0
+    per_gen = []
+    for _ in range(args.steps):
+        toks, tps, timed, secs = tr.generate_ids(PROMPT_IDS, ntok)
+        timed_tokens += timed
+        per_gen.append(tps)
+        if tokens0 is None:
+            tokens0 = toks
+    barrier()
+    elapsed = time.perf_counter() - t0
+    total_tokens = timed_tokens
+    if use_dist:
+        import torch
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tk = torch.tensor([timed_tokens], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        total_tokens = int(tk.item())
+    value = total_tokens / elapsed
+
+    # ---- per-kernel durations (dispatch timestamps, ring over the layers' weights) ------------------
+    kb = kernel_bytes(cfg)
+    kernels = {}
+    roofline = None
+    if rank == 0:
+        for kid, (name, nbytes) in kb.items():
+            tr.bench_kernel(kid, 32)   # warm
+            avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
+            kernels[name] = {"us": round(avg, 3), "min_us": round(mn, 3), "bytes": nbytes, "GBps": round(nbytes / avg / 1e3, 1)}
+        dom = kernels[kb[0][0]]
+        roofline = {"bound": "hbm", "kernel": kb[0][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"]}
+        int4_bytes = sum(kb[k][1] for k in (0, 2, 3, 4))
+        int4_us = sum(kernels[kb[k][0]]["us"] for k in (0, 2, 3, 4))
+        kernels["int4_gemv_all_per_layer"] = {"us": round(int4_us, 3), "bytes": int4_bytes, "GBps": round(int4_bytes / int4_us / 1e3, 1)}
+
+    # ---- CPU baseline (rank 0, N == 1 only): the oracle restating run_llama_network ------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle
+        m = oracle.Model(path)
+        nthreads = oracle.lib().orc_num_threads()
+        t0 = time.perf_counter()
+        n_done = 0
+        ctoks = list(PROMPT_IDS)
+        worst = 0.0
+        agree = 0
+        tr.reset(PROMPT_IDS)
+        for pos in range(min(args.cpu_steps, ntok)):
+            ref = m.forward(ctoks[pos], pos)
+            n_done += 1
+            if pos >= len(PROMPT_IDS) - 1:
+                ctoks.append(int(np.argmax(ref.astype(np.float32))))
+            if time.perf_counter() - t0 > 40:
+                break
+        cpu_secs = time.perf_counter() - t0
+        # parity of the same positions on the GPU (not timed)
+        tr.reset(PROMPT_IDS)
+        m2_tokens = []
+        for pos in range(n_done):
+            tr.run_transformer(pos >= len(PROMPT_IDS) - 1)
+            api.synchronize()
+        glog = tr.logits().astype(np.float32)
+        rlog = ref.astype(np.float32)
+        worst = float(np.max(np.abs(glog - rlog) / np.maximum(1.0, np.abs(rlog))))
+        agree = int(sum(int(tr.token(i)) == ctoks[i] for i in range(len(PROMPT_IDS), min(len(ctoks), n_done + 1))))
+        parity = {"positions": n_done, "last_logits_max_rel_err": round(worst, 5),
+                  "greedy_tokens_agree": "%d/%d" % (agree, max(0, min(len(ctoks), n_done + 1) - len(PROMPT_IDS)))}
+        cpu = {"value": round(n_done / cpu_secs, 4), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+               "sample": "%d decode steps (positions 0..%d) of the same %s checkpoint, CPU restatement of run_llama_network "
+                         "(oracle/q4_oracle.c, OpenMP); the reference has no CPU path" % (n_done, n_done - 1, args.model)}
+        m.close()
+
+    if rank == 0:
+        name, cus, mem = api.device_info()
+        out = {
+            "metric": "decode_tokens_per_sec", "value": round(value, 2), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / max(args.steps, 1), 3),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / PUBLISHED_TOKS, 3),
+            "baseline_note": "published 200.79 tok/s is the reference on an RTX 4090 (README.md:111); no MI355X number exists",
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Llama-2-%s AWQ w4 g128 (synthetic weights, real geometry), -n %d greedy, 8-token prompt, "
+                                   "%d timed tokens per step" % (args.model.upper(), ntok, timed_tokens // max(args.steps, 1)),
+                       "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "vocab_size": cfg.vocab_size,
+                       "parallelism": "replicas x%d (no data-path collective)" % world},
+            "ms_per_token": round(1000.0 * elapsed * world / max(total_tokens, 1), 4),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "parity_vs_cpu_restatement": parity,
+            "device": name, "cus": cus, "load_s": round(t_load, 2), "synth_s": round(t_gen, 2),
+            "tok_s_per_generation": [round(x, 1) for x in per_gen],
+        }
+        print(json.dumps(out))
+    tr.close()
+    L.q4_set_stream(None)
+    L.q4_stream_destroy(stream)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

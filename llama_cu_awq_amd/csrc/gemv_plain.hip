@@ -1,0 +1,18 @@
+// gemv_plain.hip -- instantiations of the int4 GEMV for mat_vec_kernel_int4 (gpu_kernels.h:235-240)
+#include "gemv_q4.h"
+namespace q4 {
+int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
+#define Q4_CASE(S, C) if (slots == S && cols == C) return launch_one<MODE_PLAIN, S, C, false>(a, waves);
+    const int slots = pick_slots(a.nslots);
+    if (cols != 1 && cols != 2 && cols != 4) cols = 2;
+    if (slots >= 6 && cols == 4) cols = 2;   // 6x4 uint4 per lane does not fit the register file
+    Q4_CASE(2, 1) Q4_CASE(2, 2) Q4_CASE(2, 4)
+    Q4_CASE(3, 1) Q4_CASE(3, 2) Q4_CASE(3, 4)
+    Q4_CASE(4, 1) Q4_CASE(4, 2) Q4_CASE(4, 4)
+    Q4_CASE(6, 1) Q4_CASE(6, 2)
+    Q4_CASE(7, 1) Q4_CASE(7, 2)
+    Q4_CASE(8, 1) Q4_CASE(8, 2)
+#undef Q4_CASE
+    return Q4_ERR_UNSUPPORTED_SIZE;
+}
+}  // namespace q4

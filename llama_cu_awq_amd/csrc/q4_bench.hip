@@ -1,0 +1,51 @@
+// q4_bench.hip -- per-kernel timing with dispatch timestamps over a ring of distinct weight sets (bench.py).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "q4_internal.h"
+using namespace q4;
+
+extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
+                                  double* min_us, double* max_us) {
+    if (iters < 1 || !p || !s || !w) return -1.0;
+    const int dim = p->dim, hidden = p->hidden_dim;
+    const int head_size = dim / p->n_heads;
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    std::vector<hipEvent_t> ev(2 * iters);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return -1.0;
+    int rc = 0;
+    for (int i = 0; i < iters && !rc; i++) {
+        const PerLayerWeight* L = &w->layers[i % w->num_layers];   // ring: a different layer's weights every launch
+        const int loff = (i % w->num_layers) * p->seq_len * kv_dim;
+        g_ev_start = ev[2 * i];
+        g_ev_stop = ev[2 * i + 1];
+        switch (kernel_id) {
+            case 0: rc = launch_ffn_fused(s->hb, s->x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden); break;
+            case 1: rc = q4_matmul_q4(s->hb, s->xb, &L->wq_gate, dim, hidden, 0, -1, nullptr); break;
+            case 2: rc = q4_matmul_q4(s->xb, s->hb, &L->wq_down, hidden, dim, 1, -1, nullptr); break;
+            case 3: rc = launch_qkv_fused(s->q, s->key_cache, s->value_cache, s->x, L->rms_att_weight, &L->wq_q, &L->wq_k,
+                                          &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta); break;
+            case 4: rc = q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr); break;
+            case 5: rc = q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f); break;
+            case 6: rc = q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads,
+                                                 head_size, p->n_heads / p->n_kv_heads, p->seq_len, s->pos); break;
+            default: rc = Q4_ERR_ARG;
+        }
+    }
+    g_ev_start = g_ev_stop = nullptr;
+    double total = 0, mn = 1e30, mx = 0;
+    if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) rc = Q4_ERR_HIP;
+    for (int i = 0; i < iters && !rc; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = Q4_ERR_HIP; break; }
+        const double us = ms * 1000.0;
+        total += us;
+        if (us < mn) mn = us;
+        if (us > mx) mx = us;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    if (rc) return -1.0;
+    if (min_us) *min_us = mn;
+    if (max_us) *max_us = mx;
+    return total / iters;
+}

@@ -1,0 +1,114 @@
+// q4_device.h -- wave64 / gfx950 device helpers shared by all kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q4 {
+
+typedef _Float16 f16_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int as_i(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float as_f(int v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ h2 as_h2(unsigned v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ unsigned as_u(h2 v) { return __builtin_bit_cast(unsigned, v); }
+
+__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }   // RNE
+__device__ __forceinline__ float round_h(float f) { return (float)(f16_t)f; }
+
+// DPP cross-lane move (wave64, 16-lane rows). CTRL: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return as_f(__builtin_amdgcn_update_dpp(0, as_i(v), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce inside each 16-lane DPP row: every lane ends with its row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return as_f(__builtin_amdgcn_readlane(as_i(v), lane));
+}
+
+// full 64-lane sum, result wave-uniform. Fixed order: 4 DPP steps per row, then (r0+r1)+(r2+r3).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
+// streamed-once weights: non-temporal 128-bit load (global_load_dwordx4 ... nt)
+__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// sum of squares of 8 packed halves, sequential fma chain (canonical order for rmsnorm)
+__device__ __forceinline__ float sumsq8(u32x4 v, float acc) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        h2 p = as_h2(v[d]);
+        float a = (float)p.x, b = (float)p.y;
+        acc = __builtin_fmaf(a, a, acc);
+        acc = __builtin_fmaf(b, b, acc);
+    }
+    return acc;
+}
+
+// Canonical rmsnorm reduction (block-size independent, so the standalone rmsnorm kernel and every
+// fused consumer produce the same bits): per-16B-chunk partials in LDS, then ONE wave sums them
+// lane-strided by 64 and tree-reduces. `part` holds `nchunks` floats. Returns 1/sqrt(mean+eps) to all.
+// Caller: every thread has written part[] for its chunks and called __syncthreads() before.
+__device__ __forceinline__ float rms_scale_from_partials(const float* part, int nchunks, int size, float* bcast) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float s = 0.f;
+        for (int u = tid; u < nchunks; u += 64) s += part[u];
+        s = wave_sum(s);
+        if (tid == 0) {
+            float ss = s / (float)size;        // gpu_kernels.h:88
+            ss += 1e-5f;                       // :89
+            ss = 1.0f / sqrtf(ss);             // :90
+            *bcast = ss;
+        }
+    }
+    __syncthreads();
+    return *bcast;
+}
+
+// normalise 8 halves: half(x * (ss * w))   gpu_kernels.h:100-102
+__device__ __forceinline__ u32x4 rms_apply8(u32x4 xv, u32x4 wv, float ss) {
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        h2 x = as_h2(xv[d]), w = as_h2(wv[d]);
+        h2 r;
+        r.x = (f16_t)((float)x.x * (ss * (float)w.x));
+        r.y = (f16_t)((float)x.y * (ss * (float)w.y));
+        o[d] = as_u(r);
+    }
+    return o;
+}
+
+}  // namespace q4

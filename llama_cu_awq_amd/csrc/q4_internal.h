@@ -1,0 +1,70 @@
+// q4_internal.h -- shared state and helpers of libllama2_q4.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdio.h>
+#include "llama2_q4.h"
+
+namespace q4 {
+
+// replaces the reference's file-scope `cudaStream_t stream` (llama2_q4.cu:207)
+extern hipStream_t g_stream;
+extern int g_fusion;       // 1: fused sequence, 0: 1:1 reference kernel sequence
+extern int g_use_graphs;   // USE_CUDA_GRAPHS, llama2_q4.cu:33
+extern int g_quiet;
+extern char g_last_error[512];
+// when non-null every launch carries dispatch timestamps (q4_bench_kernel): hipExtLaunchKernelGGL stamps the
+// kernel's own begin/end, so the elapsed time excludes the inter-kernel gap, like rocprofv3's kernel trace
+extern hipEvent_t g_ev_start, g_ev_stop;
+
+#define Q4_LAUNCH(kernel, grid, block, smem, ...)                                                              \
+    do {                                                                                                       \
+        if (q4::g_ev_start)                                                                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, q4::g_stream, q4::g_ev_start, q4::g_ev_stop, 0,   \
+                                  __VA_ARGS__);                                                                \
+        else                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, smem, q4::g_stream, __VA_ARGS__);                          \
+    } while (0)
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define Q4_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return q4::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define Q4_LAUNCH_CHECK() Q4_HIP(hipGetLastError())
+
+static inline int divUp(int a, int b) { return (a - 1) / b + 1; }   // common.h:80-82
+
+// packed geometry of one QWeight column (llama2_q4.cu:82-98, 227-229)
+struct QGeom {
+    int K;        // inputElements
+    int N;        // opElements
+    int pw4;      // uint4 (32 weights) per column = packed_weights_height / 4
+    int pzh;      // packed_zeros_height
+    int sh;       // scales_height
+    int nslots;   // ceil(pw4 / 64): wave-wide uint4 loads per column
+};
+static inline QGeom make_geom(int K, int N) {
+    QGeom g;
+    g.K = K; g.N = N;
+    g.pw4 = divUp(K, 32);
+    g.sh = divUp(K, Q4_GROUP_SIZE);
+    g.pzh = divUp(g.sh, 8);
+    g.nslots = divUp(g.pw4, 64);
+    return g;
+}
+
+// ---- internal launchers shared by the API layer and the network (all enqueue on g_stream) ----
+struct GemvTune { int cols; int waves; };   // columns per wave, waves per block
+
+// fused layer kernels (validated against the unfused chain in tests/test_fusion_gpu.py)
+int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w,
+                     const QWeight* qw, const QWeight* kw, const QWeight* vw, int dim, int kv_dim, int loff,
+                     const int* pPos, int head_size, float rope_theta);
+int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
+                     int dim, int hidden);
+
+}  // namespace q4

@@ -1,0 +1,465 @@
+// q4_kernels.hip -- the fp16 companions of the int4 GEMV, hand-written for gfx950 (wave64):
+// rmsnorm, fp16 GEMV (classifier), RoPE, single-kernel attention, embedding gather, argmax,
+// fp16->fp32 copy; plus the C-ABI launchers of include/llama2_q4.h for every kernel.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "gemv_q4.h"
+
+namespace q4 {
+
+int launch_gemv_plain(const GemvArgs& a, int cols, int waves);
+int launch_gemv_qkv(const GemvArgs& a, int cols, int waves);
+int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
+
+// launch shapes (columns per wave, waves per block); tuned on MI355X, see DESIGN.md
+enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
+static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {2, 4}, {4, 4}, {2, 4}};
+
+// ------------------------------------------------------------------------------------------------
+// rmsnorm_kernel (gpu_kernels.h:72-105). One block; 16-byte loads; the canonical chunk-partial reduction
+// of q4_device.h so that fused consumers reproduce these bits exactly.
+__global__ void __launch_bounds__(256) rmsnorm_kernel(q4_half* o, const q4_half* x, const q4_half* weight, int size) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* part = reinterpret_cast<float*>(smem);
+    const int nchunks = size >> 3;
+    for (int u = threadIdx.x; u < nchunks; u += blockDim.x)
+        part[u] = sumsq8(reinterpret_cast<const u32x4*>(x)[u], 0.f);
+    __syncthreads();
+    const float ss = rms_scale_from_partials(part, nchunks, size, part + nchunks);
+    for (int u = threadIdx.x; u < nchunks; u += blockDim.x)
+        reinterpret_cast<u32x4*>(o)[u] =
+            rms_apply8(reinterpret_cast<const u32x4*>(x)[u], reinterpret_cast<const u32x4*>(weight)[u], ss);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mat_vec_kernel (gpu_kernels.h:109-139): fp16 GEMV, used for the un-quantised classifier (262 MB at 7B).
+// One wave owns ROWS consecutive output rows; lane l reads uint4 j = s*64 + l of each row (1 KiB per wave
+// instruction, non-temporal); x lives in registers (same slice for every row); v_dot2c_f32_f16, fp32 acc.
+template <int ROWS, int SLOTS>
+__global__ void __launch_bounds__(256) gemv_f16_kernel(q4_half* op, const q4_half* ip, const q4_half* wt, int n, int d,
+                                                       int ip_stride, int w_stride, int op_stride, int w_row_stride,
+                                                       float alpha) {
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + wave) * ROWS;
+    if (row0 >= d) return;
+    const q4_half* input = ip + (size_t)blockIdx.y * ip_stride;
+    const q4_half* weight = wt + (size_t)blockIdx.y * w_stride;
+    q4_half* output = op + (size_t)blockIdx.y * op_stride;
+    const unsigned n8 = (unsigned)n >> 3;
+    float sum[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) sum[r] = 0.f;
+    for (unsigned s0 = 0; s0 * 64 < n8; s0 += SLOTS) {
+        u32x4 X[SLOTS], W[ROWS][SLOTS];
+        bool act[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const unsigned j = (s0 + s) * 64 + lane;
+            act[s] = j < n8;
+            const unsigned jj = act[s] ? j : n8 - 1;
+            X[s] = reinterpret_cast<const u32x4*>(input)[jj];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int row = row0 + r < d ? row0 + r : d - 1;
+                W[r][s] = ld_nt(reinterpret_cast<const u32x4*>(weight + (size_t)row * w_row_stride) + jj);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++)
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_fdot2(as_h2(W[r][s][e]), as_h2(X[s][e]), acc, false);
+                sum[r] += act[s] ? acc : 0.f;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        float t = wave_sum(sum[r]);
+        t *= alpha;                                                   // gpu_kernels.h:135
+        if (lane == 0 && row0 + r < d) output[row0 + r] = f2h(t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPERotation_kernel (gpu_kernels.h:332-355), one block per head, head_size/2 threads.
+__global__ void rope_kernel(q4_half* sq, q4_half* sk_base, int num_kv_heads, int head_size, const int* pPos, int loff,
+                            float rope_theta) {
+    const int pos = *pPos;
+    const int h = blockIdx.x;
+    q4_half* q = sq + (size_t)h * head_size;
+    const int i = threadIdx.x;
+    const int head_dim = (i * 2) % head_size;
+    const float freq = 1.0f / powf(rope_theta, head_dim / (float)head_size);
+    const float val = pos * freq;
+    const float fcr = cosf(val), fci = sinf(val);
+    const float q0 = h2f(q[i]), q1 = h2f(q[i + head_size / 2]);
+    q[i] = f2h(q0 * fcr - q1 * fci);
+    q[i + head_size / 2] = f2h(q0 * fci + q1 * fcr);
+    if (h < num_kv_heads) {
+        q4_half* k = sk_base + (size_t)loff + (size_t)pos * num_kv_heads * head_size + (size_t)h * head_size;
+        const float k0 = h2f(k[i]), k1 = h2f(k[i + head_size / 2]);
+        k[i] = f2h(k0 * fcr - k1 * fci);
+        k[i + head_size / 2] = f2h(k0 * fci + k1 * fcr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MultiHeadAttention (llama2_q4.cu:267-284) as ONE kernel per layer: block = one head, 16 waves.
+// A K/V row of a head is head_size halves = LPR lanes x 16 B, so one wave instruction fetches 64/LPR
+// positions, coalesced. Pass 1 scores -> LDS (fp32, rounded through fp16 like the reference's `att`,
+// gpu_kernels.h:167), block max / exp / sum (:373-396), pass 2 probabilities (rounded through fp16, :400)
+// times V (:311). Scores never leave the CU; `att` in HBM is not touched.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    if (LPR >= 8) v += dpp_mov<0x141>(v);
+    if (LPR >= 16) v += dpp_mov<0x140>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16);
+    return v;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    // red: 16 floats + 1. all threads participate.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();                       // previous users of red[] are done
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < nw; w++) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(1024) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
+                                                         const q4_half* value_cache, int head_size, int kv_mul,
+                                                         int kv_dim, const int* pPos, float alpha, int lds_scores) {
+    constexpr int R = 64 / LPR;            // positions per wave instruction
+    constexpr int U = 4;                   // wave instructions in flight per pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);             // 32 floats
+    float* sc = red + 32;                                    // [lds_scores] scores / exps
+    const int h = blockIdx.x;
+    const int size = *pPos + 1;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = tid >> 6, nw = blockDim.x >> 6;
+    const int row = lane / LPR, sub = lane % LPR;            // position within the instruction, 16-B slice of the row
+    const int stride = nw * R;                               // positions per block step
+    const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
+
+    // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
+    for (int tb = wave * R; tb < size; tb += stride * U) {
+        u32x4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + row + u * stride;
+            const int tc = t < size ? t : size - 1;
+            kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + row + u * stride;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
+            s = row_sum<LPR>(s);
+            s *= alpha;
+            if (sub == 0 && t < size) sc[t] = round_h(s);                         // gpu_kernels.h:167
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
+    float m = -INFINITY;
+    for (int t = tid; t < size; t += blockDim.x) m = fmaxf(m, sc[t]);
+    m = block_reduce(m, red, true);
+    float sum = 0.f;
+    for (int t = tid; t < size; t += blockDim.x) {
+        const float e = expf(sc[t] - m);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = block_reduce(sum, red, false);      // barriers inside also publish sc[]
+
+    // ---- pass 2: att . V -----------------------------------------------------------------------------
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    for (int tb = wave * R; tb < size; tb += stride * U) {
+        u32x4 vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + row + u * stride;
+            const int tc = t < size ? t : size - 1;
+            vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + row + u * stride;
+            const float p = t < size ? round_h(sc[t] / sum) : 0.f;                // gpu_kernels.h:400
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const h2 v2 = as_h2(vv[u][e]);
+                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);          // :311
+                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+            }
+        }
+    }
+    // combine the R rows of a wave (DPP/shuffle across row groups), then the waves through LDS
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v = acc[e];
+        if (LPR <= 32) v += __shfl_xor(v, 32);
+        if (LPR <= 16) v += __shfl_xor(v, 16);
+        if (LPR <= 8) v += __shfl_xor(v, 8);
+        if (LPR <= 4) v += __shfl_xor(v, 4);
+        acc[e] = v;
+    }
+    __syncthreads();                          // everyone is done reading sc[]
+    float* outp = sc;                         // reuse: [nw][head_size]
+    if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int n = tid; n < head_size; n += blockDim.x) {
+        float s = 0.f;
+        for (int w = 0; w < nw; w++) s += outp[w * head_size + n];
+        output[(size_t)h * head_size + n] = f2h(s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// copy_embedding_kernel (gpu_kernels.h:61-69); 16-byte copies. tokens may live in mapped host memory.
+__global__ void copy_embedding_kernel(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (size >> 3)) return;
+    const int pos = *pPos;
+    const int token = tokens[pos];
+    reinterpret_cast<u32x4*>(x)[u] = reinterpret_cast<const u32x4*>(table + (size_t)token * size)[u];
+}
+
+// convert_fp16_to_fp32 (gpu_kernels.h:55-59). pos_stride != 0: out += *pPos * pos_stride (logits_array slot,
+// llama2_q4.cu:380) so the launch is capturable in a graph.
+__global__ void convert_fp16_to_fp32_kernel(float* out, const q4_half* in, int elements, const int* pPos,
+                                            int pos_stride) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pPos) out += (size_t)(*pPos) * pos_stride;
+    if (index < elements) out[index] = h2f(in[index]);
+}
+
+// argmax_kernel (gpu_kernels.h:448-493). Ties resolve to the LOWEST index (the reference's tie-break is a
+// benign race; lowest index is one of its legal outcomes and matches the oracle).
+__global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size, int* result, volatile int* pPos,
+                                                      int* pPosGpu, int write_token) {
+    __shared__ float sval[16];
+    __shared__ int sidx[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float max_val = -INFINITY;
+    int max_pos = 0x7fffffff;
+    for (int i = tid; i < size; i += blockDim.x) {
+        const float v = h2f(x[i]);
+        if (v > max_val) { max_val = v; max_pos = i; }
+    }
+    // wave argmax by butterfly (value, then lower index)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(max_val, off);
+        const int op = __shfl_xor(max_pos, off);
+        if (ov > max_val || (ov == max_val && op < max_pos)) { max_val = ov; max_pos = op; }
+    }
+    if (lane == 0) { sval[wave] = max_val; sidx[wave] = max_pos; }
+    __syncthreads();
+    if (tid == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++)
+            if (sval[w] > max_val || (sval[w] == max_val && sidx[w] < max_pos)) { max_val = sval[w]; max_pos = sidx[w]; }
+        if (max_pos == 0x7fffffff) max_pos = 0;          // all NaN / -inf
+        int token_pos = *pPos;
+        token_pos++;
+        if (write_token) result[token_pos] = max_pos;    // :486-487
+        *pPos = token_pos;                               // :490 (unblocks the CPU)
+        *pPosGpu = token_pos;                            // :491
+    }
+}
+
+// ---- fused-path launchers used by the network -----------------------------------------------------
+static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
+
+static int fill_geom(GemvArgs& a, int K, int N) {
+    if ((K & 7) || (N & 7)) return Q4_ERR_UNSUPPORTED_SIZE;      // llama2_q4.cu:225
+    if (K % 32) return Q4_ERR_UNSUPPORTED_SIZE;                   // packed height must be whole uint4
+    QGeom g = make_geom(K, N);
+    a.K = K; a.N = N; a.pw4 = g.pw4; a.pzh = g.pzh; a.sh = g.sh; a.nslots = g.nslots;
+    if (pick_slots(g.nslots) == 0) return Q4_ERR_UNSUPPORTED_SIZE;   // K > 16384: not instantiated
+    return Q4_OK;
+}
+
+int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w, const QWeight* qw,
+                     const QWeight* kw, const QWeight* vw, int dim, int kv_dim, int loff, const int* pPos,
+                     int head_size, float rope_theta) {
+    if (dim != kv_dim) return Q4_ERR_ARG;
+    GemvArgs a = {};
+    int rc = fill_geom(a, dim, dim);
+    if (rc) return rc;
+    fill_mat(a.m[0], qw); fill_mat(a.m[1], kw); fill_mat(a.m[2], vw);
+    a.out[0] = q; a.out[1] = kc; a.out[2] = vc;
+    a.x = x; a.rms_w = rms_w; a.pPos = pPos; a.loff = loff;
+    a.rope = head_size > 0; a.head_size = head_size > 0 ? head_size : 2; a.rope_theta = rope_theta;
+    return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
+}
+
+int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
+                     int dim, int hidden) {
+    GemvArgs a = {};
+    int rc = fill_geom(a, dim, hidden);
+    if (rc) return rc;
+    fill_mat(a.m[0], gate); fill_mat(a.m[1], up);
+    a.out[0] = out; a.x = x; a.rms_w = rms_w;
+    return launch_gemv_ffn(a, g_tune[TUNE_FFN].cols, g_tune[TUNE_FFN].waves);
+}
+
+}  // namespace q4
+
+using namespace q4;
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+void q4_set_gemv_tune(int kind, int cols, int waves) {
+    if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }
+}
+
+int q4_rmsnorm(q4_half* o, const q4_half* x, const q4_half* weight, int size) {
+    if (size & 7) return Q4_ERR_UNSUPPORTED_SIZE;
+    const size_t smem = (size_t)(size >> 3) * 4 + 16;
+    Q4_LAUNCH(rmsnorm_kernel, dim3(1), dim3(256), smem, o, x, weight, size);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_matmul_f16(q4_half* xout, const q4_half* x, const q4_half* w, int n, int d, int batch, int x_stride, int w_stride,
+                  int op_stride, int w_row_stride, float alpha) {
+    if ((n & 7) || (d & 7)) return Q4_ERR_UNSUPPORTED_SIZE;                         // llama2_q4.cu:215
+    if (w_row_stride == -1) w_row_stride = n;                                       // :220
+    if (w_row_stride & 7) return Q4_ERR_UNSUPPORTED_SIZE;
+    constexpr int ROWS = 2, WAVES = 4;
+    dim3 grid(divUp(d, ROWS * WAVES), batch);
+    if (n <= 2048)
+        Q4_LAUNCH((gemv_f16_kernel<ROWS, 4>), grid, dim3(WAVES * 64), 0, xout, x, w, n, d, x_stride,
+                           w_stride, op_stride, w_row_stride, alpha);
+    else
+        Q4_LAUNCH((gemv_f16_kernel<ROWS, 8>), grid, dim3(WAVES * 64), 0, xout, x, w, n, d, x_stride,
+                           w_stride, op_stride, w_row_stride, alpha);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_matmul_q4(q4_half* xout, const q4_half* x, const QWeight* w, int inpSize, int opSize, int accum, int loff,
+                 const int* pPos) {
+    GemvArgs a = {};
+    int rc = fill_geom(a, inpSize, opSize);
+    if (rc) return rc;
+    if (loff != -1 && pPos == nullptr) return Q4_ERR_ARG;
+    fill_mat(a.m[0], w);
+    a.out[0] = xout; a.x = x; a.accum = accum; a.loff = loff; a.pPos = pPos;
+    const GemvTune& t = g_tune[a.nslots <= 2 ? TUNE_PLAIN_SMALL : TUNE_PLAIN_BIG];
+    return launch_gemv_plain(a, t.cols, t.waves);
+}
+
+int q4_qkv_matvec(q4_half* q, q4_half* key_cache, q4_half* value_cache, const q4_half* x, const QWeight* qw,
+                  const QWeight* kw, const QWeight* vw, int inpSize, int opSize, int loff, const int* pPos) {
+    GemvArgs a = {};
+    int rc = fill_geom(a, inpSize, opSize);
+    if (rc) return rc;
+    if (pPos == nullptr) return Q4_ERR_ARG;
+    fill_mat(a.m[0], qw); fill_mat(a.m[1], kw); fill_mat(a.m[2], vw);
+    a.out[0] = q; a.out[1] = key_cache; a.out[2] = value_cache;
+    a.x = x; a.pPos = pPos; a.loff = loff; a.rope = 0; a.head_size = 2;
+    return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
+}
+
+int q4_ffn_matvec_silu(q4_half* xout, const q4_half* x, const QWeight* gate_w, const QWeight* up_w, int inpSize,
+                       int opSize) {
+    return launch_ffn_fused(xout, x, nullptr, gate_w, up_w, inpSize, opSize);
+}
+
+int q4_rope_rotation(q4_half* q, q4_half* k, int num_heads, int num_kv_heads, int head_size, const int* pPos, int loff,
+                     float rope_theta) {
+    if (head_size < 2 || head_size / 2 > 1024) return Q4_ERR_UNSUPPORTED_SIZE;
+    Q4_LAUNCH(rope_kernel, dim3(num_heads), dim3(head_size / 2), 0, q, k, num_kv_heads, head_size, pPos,
+                       loff, rope_theta);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
+                            q4_half* att, int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos) {
+    (void)att;
+    const int dim = head_size * num_heads;
+    const int kv_dim = dim / kv_mul;
+    const float alpha = (float)(1.0 / sqrt((double)head_size));                     // llama2_q4.cu:273
+    constexpr int NW = 16;
+    // LDS: 32 reduction floats + max(seq scores, NW*head_size output partials) floats
+    int lds_floats = max_seq_len > NW * head_size ? max_seq_len : NW * head_size;
+    const size_t smem = (size_t)(32 + lds_floats) * 4;
+    if (smem > 160 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;                          // > ~40K positions
+    dim3 grid(num_heads), block(NW * 64);
+#define Q4_ATT(L)                                                                                                  \
+    {                                                                                                              \
+        if (smem > 64 * 1024)                                                                                      \
+            Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)smem));                                                                \
+        Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache,   \
+                           head_size, kv_mul, kv_dim, pPos, alpha, lds_floats);                                    \
+    }
+    switch (head_size) {
+        case 32: Q4_ATT(4) break;
+        case 64: Q4_ATT(8) break;
+        case 128: Q4_ATT(16) break;
+        case 256: Q4_ATT(32) break;
+        default: return Q4_ERR_UNSUPPORTED_SIZE;
+    }
+#undef Q4_ATT
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_copy_embedding(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {
+    if (size & 7) return Q4_ERR_UNSUPPORTED_SIZE;
+    Q4_LAUNCH(copy_embedding_kernel, dim3(divUp(size >> 3, 256)), dim3(256), 0, x, table, size, tokens,
+                       pPos);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_convert_fp16_to_fp32(float* out, const q4_half* in, int elements) {
+    Q4_LAUNCH(convert_fp16_to_fp32_kernel, dim3(divUp(elements, 256)), dim3(256), 0, out, in, elements,
+                       (const int*)nullptr, 0);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+// logits -> logits_array[*pPos] (llama2_q4.cu:377-382), position read on the device so it can be graph-captured
+int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos) {
+    Q4_LAUNCH(convert_fp16_to_fp32_kernel, dim3(divUp(vocab_size, 256)), dim3(256), 0, logits_array,
+                       logits, vocab_size, pPos, vocab_size);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+int q4_argmax(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, int write_token) {
+    Q4_LAUNCH(argmax_kernel, dim3(1), dim3(1024), 0, x, size, result, pPos, pPosGpu, write_token);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,596 @@
+// q4_runtime.hip -- model state, loader, per-token network, hipGraph step, sampler and token loops.
+// Mirrors llama2_q4.cu:38-202 (memory + loader), :286-340 (run_llama_network), :342-395 (run_transformer),
+// :436-492 (generate), sampler.h, perplexity.h:57-97.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <map>
+#include <vector>
+#include "q4_internal.h"
+
+namespace q4 {
+
+hipStream_t g_stream = nullptr;
+int g_fusion = 1;
+int g_use_graphs = 1;
+int g_quiet = 0;
+char g_last_error[512] = "";
+hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+    fprintf(stderr, "llama2_q4: HIP error %s\n", g_last_error);
+    return Q4_ERR_HIP;
+}
+
+// every Transformer owns two HBM slabs (weights, run state) instead of ~750 small allocations: layers sit
+// back to back in HBM in the order the token loop streams them.
+struct Slabs {
+    void* weights = nullptr;
+    void* state = nullptr;
+    void* shared = nullptr;
+    void* logits_array = nullptr;
+};
+static std::map<const Transformer*, Slabs> g_slabs;
+
+// graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
+static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][8];
+static bool g_captured[Q4_MAX_GRAPHS][8];
+static const void* g_graph_owner = nullptr;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t qweight_bytes(int height, int width, size_t* wb, size_t* zb, size_t* sb) {
+    // llama2_q4.cu:82-98
+    size_t packed_wt_height = (size_t)divUp(height, 32) * 4;
+    size_t scales_height = (size_t)divUp(height, Q4_GROUP_SIZE);
+    size_t packed_zeros_height = (size_t)divUp((int)scales_height, 8);
+    *wb = packed_wt_height * width * sizeof(uint32_t);
+    *zb = packed_zeros_height * width * sizeof(uint32_t);
+    *sb = scales_height * width * sizeof(q4_half);
+    return *wb + *zb + *sb;
+}
+
+}  // namespace q4
+
+using namespace q4;
+
+extern "C" int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos);
+
+extern "C" {
+
+const char* q4_status_string(int status) {
+    switch (status) {
+        case Q4_OK: return "ok";
+        case Q4_ERR_UNSUPPORTED_SIZE: return "Unsupported matmul size. Exiting";   // llama2_q4.cu:215
+        case Q4_ERR_ALLOC: return "malloc failed!";                                // :131
+        case Q4_ERR_IO: return "error reading weights";                            // :158
+        case Q4_ERR_HIP: return "HIP runtime error";
+        case Q4_ERR_ARG: return "invalid argument";
+    }
+    return "unknown";
+}
+const char* q4_last_error(void) { return g_last_error; }
+
+int q4_set_device(int device) { Q4_HIP(hipSetDevice(device)); return Q4_OK; }
+int q4_stream_create(q4_stream_t* out) {
+    hipStream_t s;
+    Q4_HIP(hipStreamCreate(&s));
+    *out = (q4_stream_t)s;
+    return Q4_OK;
+}
+int q4_stream_destroy(q4_stream_t s) {
+    if ((hipStream_t)s == g_stream) g_stream = nullptr;
+    Q4_HIP(hipStreamDestroy((hipStream_t)s));
+    return Q4_OK;
+}
+void q4_set_stream(q4_stream_t s) { g_stream = (hipStream_t)s; }
+q4_stream_t q4_get_stream(void) { return (q4_stream_t)g_stream; }
+int q4_stream_synchronize(void) { Q4_HIP(hipStreamSynchronize(g_stream)); return Q4_OK; }
+int q4_device_synchronize(void) { Q4_HIP(hipDeviceSynchronize()); return Q4_OK; }
+
+int q4_malloc(void** dptr, size_t bytes) { Q4_HIP(hipMalloc(dptr, bytes)); return Q4_OK; }
+int q4_free(void* dptr) { Q4_HIP(hipFree(dptr)); return Q4_OK; }
+int q4_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    Q4_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    return Q4_OK;
+}
+int q4_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    Q4_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    return Q4_OK;
+}
+int q4_memset(void* dst, int value, size_t bytes) {
+    Q4_HIP(hipMemsetAsync(dst, value, bytes, g_stream));
+    return Q4_OK;
+}
+
+void q4_set_fusion(int level) { g_fusion = level ? 1 : 0; q4_reset_graphs(); }
+int q4_get_fusion(void) { return g_fusion; }
+void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
+void q4_set_quiet(int quiet) { g_quiet = quiet; }
+
+void q4_reset_graphs(void) {
+    for (int i = 0; i < Q4_MAX_GRAPHS; i++)
+        for (int v = 0; v < 8; v++)
+            if (g_captured[i][v]) {
+                hipGraphExecDestroy(g_graphs[i][v]);
+                g_captured[i][v] = false;
+            }
+    g_graph_owner = nullptr;
+}
+
+int q4_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes) {
+    int dev = 0;
+    Q4_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    Q4_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return Q4_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// build_transformer: llama2_q4.cu:408-426 = header fread + malloc_weights (:106-134) +
+// checkpoint_init_weights (:172-202) + malloc_run_state (:38-67)
+static int read_to_device(void* dst, FILE* fp, size_t bytes, void* scratch) {
+    if (fread(scratch, 1, bytes, fp) != bytes) {                                   // readWeight :157-160
+        printf("error reading weights");
+        return Q4_ERR_IO;
+    }
+    Q4_HIP(hipMemcpy(dst, scratch, bytes, hipMemcpyHostToDevice));
+    return Q4_OK;
+}
+
+struct SlabCursor {
+    char* base;
+    size_t off;
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off = align_up(off + bytes, 256);
+        return p;
+    }
+};
+
+static void carve_qweight(SlabCursor& c, QWeight* w, int height, int width) {
+    size_t wb, zb, sb;
+    qweight_bytes(height, width, &wb, &zb, &sb);
+    w->weight = (uint32_t*)c.take(wb);
+    w->zeros = (uint32_t*)c.take(zb);
+    w->scales = (q4_half*)c.take(sb);
+}
+
+static void carve_weights(SlabCursor& c, TransformerWeights* w, const Config* p) {
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    w->token_embedding_table = (q4_half*)c.take((size_t)p->vocab_size * p->dim * sizeof(q4_half));
+    w->wcls = (q4_half*)c.take((size_t)p->vocab_size * p->dim * sizeof(q4_half));
+    w->rms_final_weight = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+    for (int l = 0; l < p->n_layers; l++) {
+        PerLayerWeight* layer = &w->layers[l];
+        carve_qweight(c, &layer->wq_q, p->dim, p->dim);
+        carve_qweight(c, &layer->wq_k, p->dim, kv_dim);
+        carve_qweight(c, &layer->wq_v, p->dim, kv_dim);
+        carve_qweight(c, &layer->wq_o, p->dim, p->dim);
+        carve_qweight(c, &layer->wq_up, p->dim, p->hidden_dim);
+        carve_qweight(c, &layer->wq_gate, p->dim, p->hidden_dim);
+        carve_qweight(c, &layer->wq_down, p->hidden_dim, p->dim);
+        layer->rms_att_weight = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+        layer->rms_ffn_weight = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+    }
+}
+
+static int upload_qweight(QWeight* w, FILE* fp, int height, int width, void* scratch) {
+    size_t wb, zb, sb;
+    qweight_bytes(height, width, &wb, &zb, &sb);
+    int rc;
+    if ((rc = read_to_device(w->weight, fp, wb, scratch))) return rc;              // uploadQWeight :162-170
+    if ((rc = read_to_device(w->zeros, fp, zb, scratch))) return rc;
+    if ((rc = read_to_device(w->scales, fp, sb, scratch))) return rc;
+    return Q4_OK;
+}
+
+int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perplexity) {
+    memset(t, 0, sizeof(*t));
+    FILE* file = fopen(checkpoint_path, "rb");
+    if (!file) { printf("Couldn't open file %s\n", checkpoint_path); return Q4_ERR_IO; }   // :412
+    if (fread(&t->config, sizeof(Config), 1, file) != 1) { printf("Invalid header size\n"); fclose(file); return Q4_ERR_IO; }
+    Config* p = &t->config;
+    if (!g_quiet)
+        printf("\nModel params:- \ndim: %d \nhidden_dim: %d\nn_heads: %d\nn_kv_heads: %d\nn_layers: %d\nseq_len: %d\nvocab_size: %d\nrope_theta: %g\n",
+               p->dim, p->hidden_dim, p->n_heads, p->n_kv_heads, p->n_layers, p->seq_len, p->vocab_size, p->rope_theta);   // :416-417
+    if (p->dim <= 0 || p->n_heads <= 0 || p->n_kv_heads <= 0 || p->n_layers <= 0 || p->vocab_size <= 0 || p->seq_len <= 0 ||
+        p->dim % p->n_heads || p->n_heads % p->n_kv_heads || (p->dim & 31) || (p->hidden_dim & 31) ||
+        p->seq_len > Q4_MAX_SEQ_LEN) {
+        printf("Unsupported model geometry\n");
+        fclose(file);
+        return Q4_ERR_UNSUPPORTED_SIZE;
+    }
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    Slabs slabs;
+    TransformerWeights* w = &t->weights;
+    w->layers = (PerLayerWeight*)calloc(p->n_layers, sizeof(PerLayerWeight));      // malloc_weights :109
+    w->num_layers = p->n_layers;
+    if (!w->layers) { printf("malloc failed!\n"); fclose(file); return Q4_ERR_ALLOC; }
+
+    // pass 1 sizes the weight slab, pass 2 hands out pointers
+    SlabCursor dry = {nullptr, 0};
+    carve_weights(dry, w, p);
+    if (hipMalloc(&slabs.weights, dry.off) != hipSuccess) { printf("malloc failed!\n"); fclose(file); return Q4_ERR_ALLOC; }
+    SlabCursor cur = {(char*)slabs.weights, 0};
+    carve_weights(cur, w, p);
+
+    // checkpoint_init_weights :172-202 (same tensor order: embedding, wcls, final norm; per layer q,k,v,o,up,gate,down,norms)
+    size_t scratch_size = (size_t)(p->vocab_size > p->hidden_dim ? p->vocab_size : p->hidden_dim) * p->dim * sizeof(q4_half);
+    void* scratch = nullptr;
+    if (hipHostMalloc(&scratch, scratch_size, hipHostMallocDefault) != hipSuccess) scratch = nullptr;
+    bool scratch_pinned = scratch != nullptr;
+    if (!scratch) scratch = malloc(scratch_size);
+    if (!g_quiet) printf("\nLoading Weights... ");
+    int rc = Q4_OK;
+    do {
+        if ((rc = read_to_device(w->token_embedding_table, file, (size_t)p->vocab_size * p->dim * sizeof(q4_half), scratch))) break;
+        if ((rc = read_to_device(w->wcls, file, (size_t)p->vocab_size * p->dim * sizeof(q4_half), scratch))) break;
+        if ((rc = read_to_device(w->rms_final_weight, file, (size_t)p->dim * sizeof(q4_half), scratch))) break;
+        for (int i = 0; i < p->n_layers && !rc; i++) {
+            PerLayerWeight* L = &w->layers[i];
+            if ((rc = upload_qweight(&L->wq_q, file, p->dim, p->dim, scratch))) break;
+            if ((rc = upload_qweight(&L->wq_k, file, p->dim, kv_dim, scratch))) break;
+            if ((rc = upload_qweight(&L->wq_v, file, p->dim, kv_dim, scratch))) break;
+            if ((rc = upload_qweight(&L->wq_o, file, p->dim, p->dim, scratch))) break;
+            if ((rc = upload_qweight(&L->wq_up, file, p->dim, p->hidden_dim, scratch))) break;      // :191 up first
+            if ((rc = upload_qweight(&L->wq_gate, file, p->dim, p->hidden_dim, scratch))) break;    // :192
+            if ((rc = upload_qweight(&L->wq_down, file, p->hidden_dim, p->dim, scratch))) break;
+            if ((rc = read_to_device(L->rms_att_weight, file, (size_t)p->dim * sizeof(q4_half), scratch))) break;
+            if ((rc = read_to_device(L->rms_ffn_weight, file, (size_t)p->dim * sizeof(q4_half), scratch))) break;
+        }
+    } while (0);
+    if (scratch_pinned) hipHostFree(scratch); else free(scratch);
+    fclose(file);
+    if (rc) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }
+    if (!g_quiet) printf("done!\n");
+
+    // malloc_run_state :38-67. att holds n_heads*max(seq_len, dim) halves (the reference's n_heads*dim overflows
+    // for seq_len > dim); this build's attention does not use it at all.
+    RunState* s = &t->state;
+    SlabCursor sd = {nullptr, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        SlabCursor& c = pass == 0 ? sd : cur;
+        if (pass == 1) {
+            if (hipMalloc(&slabs.state, sd.off) != hipSuccess) { printf("malloc failed for allocaing run state!\n"); rc = Q4_ERR_ALLOC; break; }
+            cur = {(char*)slabs.state, 0};
+            hipMemset(slabs.state, 0, sd.off);
+        }
+        s->x = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+        s->xb = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+        s->hb = (q4_half*)c.take((size_t)p->hidden_dim * sizeof(q4_half));
+        s->q = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
+        s->att = (q4_half*)c.take((size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half));
+        s->logits = (q4_half*)c.take((size_t)p->vocab_size * sizeof(q4_half));
+        s->key_cache = (q4_half*)c.take(sizeof(q4_half) * p->n_layers * p->seq_len * kv_dim);
+        s->value_cache = (q4_half*)c.take(sizeof(q4_half) * p->n_layers * p->seq_len * kv_dim);
+        s->pos = (int*)c.take(sizeof(int));
+    }
+    if (!rc && hipHostMalloc(&slabs.shared, sizeof(SharedData), hipHostMallocMapped) != hipSuccess) {   // cudaMallocHost :50
+        printf("malloc failed for allocaing run state!\n");
+        rc = Q4_ERR_ALLOC;
+    }
+    if (!rc) {
+        s->shared_data = (SharedData*)slabs.shared;
+        s->shared_data->pos = 0;
+        memset((void*)s->shared_data->tokens, 0, sizeof(int) * 16);
+    }
+    if (!rc && perplexity) {                                                       // :60-66
+        if (hipMalloc(&slabs.logits_array, sizeof(float) * p->seq_len * p->vocab_size) != hipSuccess) {
+            printf("malloc failed for allocaing logits_array!\n");
+            rc = Q4_ERR_ALLOC;
+        }
+        s->logits_array = (float*)slabs.logits_array;
+    }
+    if (rc) {
+        if (slabs.weights) hipFree(slabs.weights);
+        if (slabs.state) hipFree(slabs.state);
+        if (slabs.shared) hipHostFree(slabs.shared);
+        free(w->layers);
+        memset(t, 0, sizeof(*t));
+        return rc;
+    }
+    g_slabs[t] = slabs;
+    return Q4_OK;
+}
+
+void q4_free_transformer(Transformer* t) {                                        // :428-432
+    if (!t) return;
+    if (g_graph_owner == t) q4_reset_graphs();
+    auto it = g_slabs.find(t);
+    if (it != g_slabs.end()) {
+        hipDeviceSynchronize();
+        if (it->second.weights) hipFree(it->second.weights);
+        if (it->second.state) hipFree(it->second.state);
+        if (it->second.shared) hipHostFree(it->second.shared);
+        if (it->second.logits_array) hipFree(it->second.logits_array);
+        g_slabs.erase(it);
+    }
+    free(t->weights.layers);
+    memset(t, 0, sizeof(*t));
+}
+
+Transformer* q4_transformer_new(const char* checkpoint_path, int perplexity, int* status) {
+    Transformer* t = (Transformer*)calloc(1, sizeof(Transformer));
+    int rc = q4_build_transformer(t, checkpoint_path, perplexity);
+    if (status) *status = rc;
+    if (rc) { free(t); return nullptr; }
+    // q4_build_transformer registered the slabs under `t` already
+    return t;
+}
+void q4_transformer_delete(Transformer* t) {
+    if (!t) return;
+    q4_free_transformer(t);
+    free(t);
+}
+const Config* q4_transformer_config(const Transformer* t) { return &t->config; }
+RunState* q4_transformer_state(Transformer* t) { return &t->state; }
+TransformerWeights* q4_transformer_weights(Transformer* t) { return &t->weights; }
+
+// ---------------------------------------------------------------------------------------------------
+// run_llama_network, llama2_q4.cu:286-340
+#define Q4_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+
+int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin) {
+    q4_half* x = s->x;
+    const int dim = p->dim;
+    const int hidden_dim = p->hidden_dim;
+    const int head_size = dim / p->n_heads;
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    const int kv_mul = p->n_heads / p->n_kv_heads;
+
+    Q4_TRY(q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));       // :294
+
+    for (int l = 0; l < p->n_layers; l++) {
+        const PerLayerWeight* L = &w->layers[l];
+        const int loff = l * p->seq_len * kv_dim;                                                      // :303
+        if (g_fusion && dim == kv_dim) {
+            // rmsnorm (:300) + qkv (:307) + RoPE (:317) in one launch
+            Q4_TRY(launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
+                                    dim, kv_dim, loff, pPos, head_size, p->rope_theta));
+        } else {
+            Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_att_weight, dim));                                      // :300
+            if (dim == kv_dim) {
+                Q4_TRY(q4_qkv_matvec(s->q, s->key_cache, s->value_cache, s->xb, &L->wq_q, &L->wq_k, &L->wq_v, dim, dim, loff, pPos));
+            } else {
+                Q4_TRY(q4_matmul_q4(s->q, s->xb, &L->wq_q, dim, dim, 0, -1, nullptr));                 // :310-312
+                Q4_TRY(q4_matmul_q4(s->key_cache, s->xb, &L->wq_k, dim, kv_dim, 0, loff, pPos));
+                Q4_TRY(q4_matmul_q4(s->value_cache, s->xb, &L->wq_v, dim, kv_dim, 0, loff, pPos));
+            }
+            Q4_TRY(q4_rope_rotation(s->q, s->key_cache, p->n_heads, p->n_kv_heads, head_size, pPos, loff, p->rope_theta));   // :317
+        }
+        Q4_TRY(q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads,
+                                       head_size, kv_mul, seq_len_bin, pPos));                          // :320
+        Q4_TRY(q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                         // :323
+        if (g_fusion) {
+            Q4_TRY(launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
+        } else {
+            Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_ffn_weight, dim));                                      // :326
+            Q4_TRY(q4_ffn_matvec_silu(s->hb, s->xb, &L->wq_gate, &L->wq_up, dim, hidden_dim));         // :329
+        }
+        Q4_TRY(q4_matmul_q4(s->x, s->hb, &L->wq_down, hidden_dim, dim, 1, -1, nullptr));               // :332
+    }
+    Q4_TRY(q4_rmsnorm(x, x, w->rms_final_weight, dim));                                                // :336
+    Q4_TRY(q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));         // :339
+    return Q4_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sampler.h
+int build_sampler(Sampler* sampler, int vocab_size, float temperature, float topp, unsigned long long rng_seed) {
+    memset(sampler, 0, sizeof(*sampler));
+    sampler->vocab_size = vocab_size;
+    sampler->temperature = temperature;
+    sampler->topp = topp;
+    sampler->rng_state = rng_seed;
+    Q4_HIP(hipMalloc((void**)&sampler->indices, vocab_size * sizeof(int)));        // sampler.h:22
+    return Q4_OK;
+}
+void destroy_sampler(Sampler* sampler) {
+    if (sampler->indices) hipFree(sampler->indices);
+    if (sampler->tempStorage_sort) hipFree(sampler->tempStorage_sort);
+    if (sampler->tempStorage_scan) hipFree(sampler->tempStorage_scan);
+    memset(sampler, 0, sizeof(*sampler));
+}
+unsigned int random_u32(unsigned long long* state) {                               // sampler.h:31-37
+    *state ^= *state >> 12;
+    *state ^= *state << 25;
+    *state ^= *state >> 27;
+    return (unsigned int)((*state * 0x2545F4914F6CDD1Dull) >> 32);
+}
+float random_f32(unsigned long long* state) { return (random_u32(state) >> 8) / 16777216.0f; }   // :38-40
+
+Sampler* q4_sampler_new(int vocab_size, float temperature, float topp, unsigned long long rng_seed) {
+    Sampler* s = (Sampler*)calloc(1, sizeof(Sampler));
+    if (build_sampler(s, vocab_size, temperature, topp, rng_seed)) { free(s); return nullptr; }
+    return s;
+}
+void q4_sampler_delete(Sampler* s) {
+    if (!s) return;
+    destroy_sampler(s);
+    free(s);
+}
+
+int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin);   // q4_sampling.hip
+
+static bool sampler_is_greedy(const Sampler* sampler, int gen_token) {
+    return sampler->temperature == 0.0f || !gen_token;                             // sampler.h:47
+}
+
+// sample(), sampler.h:43-82. `launch_argmax` false when the captured graph already contains it.
+static int sample_impl(Sampler* sampler, RunState* s, int gen_token, bool launch_argmax) {
+    float coin = random_f32(&sampler->rng_state);                                  // :45, drawn every step (P8)
+    if (sampler_is_greedy(sampler, gen_token)) {
+        if (launch_argmax)
+            return q4_argmax(s->logits, sampler->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+        return Q4_OK;
+    }
+    return q4_sample_topp_device(sampler, s, coin);
+}
+int q4_sample(Sampler* sampler, RunState* s, int gen_token) { return sample_impl(sampler, s, gen_token, true); }
+
+// ---------------------------------------------------------------------------------------------------
+// run_transformer, llama2_q4.cu:346-395
+int q4_run_transformer(int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
+                       Sampler* pSampler) {
+    const int seq_len = s->shared_data->pos + 1;                                   // :354
+    const bool greedy = sampler_is_greedy(pSampler, gen_token);
+    int graphIndex;
+    int seq_len_bin = 128;
+    for (graphIndex = 0; graphIndex < Q4_MAX_GRAPHS - 1; seq_len_bin *= 2, graphIndex++)
+        if (seq_len <= seq_len_bin) break;                                         // :356-359
+    if ((seq_len > seq_len_bin) || (graphIndex == Q4_MAX_GRAPHS - 1)) seq_len_bin = p->seq_len;   // :360
+
+    if (g_use_graphs) {
+        if (g_graph_owner != (const void*)s) { q4_reset_graphs(); g_graph_owner = s; }
+        // Unlike the reference, the greedy sampler kernel and the fp32 logits copy are part of the captured
+        // graph (one launch per token instead of up to three); the variant index keeps them apart.
+        const int variant = (gen_token ? 1 : 0) | (copyLogits ? 2 : 0) | (greedy ? 0 : 4);
+        if (!g_captured[graphIndex][variant]) {                                    // :362-371
+            hipGraph_t graph = nullptr;
+            Q4_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
+            int rc = q4_run_llama_network(s->pos, p, s, w, seq_len_bin);
+            if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
+            if (!rc && greedy)
+                rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+            hipError_t e = hipStreamEndCapture(g_stream, &graph);
+            if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+            Q4_HIP(e);
+            Q4_HIP(hipGraphInstantiate(&g_graphs[graphIndex][variant], graph, nullptr, nullptr, 0));
+            Q4_HIP(hipGraphDestroy(graph));
+            g_captured[graphIndex][variant] = true;
+        }
+        Q4_HIP(hipGraphLaunch(g_graphs[graphIndex][variant], g_stream));          // :372
+        return sample_impl(pSampler, s, gen_token, false);                         // :384 (argmax already in the graph)
+    }
+    Q4_TRY(q4_run_llama_network(s->pos, p, s, w, seq_len));                       // :374
+    if (copyLogits) Q4_TRY(q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos));   // :377-382
+    return sample_impl(pSampler, s, gen_token, true);
+}
+
+// ---------------------------------------------------------------------------------------------------
+int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens) {
+    Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    s->shared_data->pos = 0;                                                       // :462
+    if (prompt_tokens && num_prompt_tokens > 0)
+        memcpy((void*)s->shared_data->tokens, prompt_tokens, sizeof(int) * num_prompt_tokens);   // :463
+    return Q4_OK;
+}
+int q4_shared_pos(const RunState* s) { return s->shared_data->pos; }
+int q4_shared_token(const RunState* s, int index) { return s->shared_data->tokens[index]; }
+
+int q4_get_logits(const Transformer* t, q4_half* host_out) {
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    Q4_HIP(hipMemcpy(host_out, t->state.logits, (size_t)t->config.vocab_size * sizeof(q4_half), hipMemcpyDeviceToHost));
+    return Q4_OK;
+}
+int q4_get_kv_row(const Transformer* t, int layer, int pos, q4_half* host_k, q4_half* host_v) {
+    const Config* p = &t->config;
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    const size_t off = (size_t)layer * p->seq_len * kv_dim + (size_t)pos * kv_dim;
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    Q4_HIP(hipMemcpy(host_k, t->state.key_cache + off, (size_t)kv_dim * sizeof(q4_half), hipMemcpyDeviceToHost));
+    Q4_HIP(hipMemcpy(host_v, t->state.value_cache + off, (size_t)kv_dim * sizeof(q4_half), hipMemcpyDeviceToHost));
+    return Q4_OK;
+}
+int q4_get_logits_array(const Transformer* t, int num_pos, float* host_out) {
+    if (!t->state.logits_array) return Q4_ERR_ARG;
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    Q4_HIP(hipMemcpy(host_out, t->state.logits_array, (size_t)num_pos * t->config.vocab_size * sizeof(float), hipMemcpyDeviceToHost));
+    return Q4_OK;
+}
+
+static long time_in_ms() {                                                         // llama2_q4.cu:400-405
+    struct timespec time;
+    timespec_get(&time, TIME_UTC);
+    return time.tv_sec * 1000 + time.tv_nsec / 1000000;
+}
+
+// generate() llama2_q4.cu:436-492 on token ids (no tokenizer, no printing): same loop order -- synchronise,
+// launch step `pos`, then look at the token produced by the PREVIOUS step; same throughput rule (pos-1)/elapsed.
+double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_tokens, int num_prompt_tokens, int steps,
+                       int* out_tokens, int* timed_tokens_out, double* seconds_out) {
+    if (num_prompt_tokens < 1) return -1.0;
+    if (steps <= 0 || steps > t->config.seq_len) steps = t->config.seq_len;        // :690
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int pos = 0;
+    if (q4_reset_sequence(&t->state, prompt_tokens, num_prompt_tokens)) return -1.0;
+    while (pos < steps) {
+        if (hipStreamSynchronize(g_stream) != hipSuccess) return -1.0;             // :468
+        if (q4_run_transformer(pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+        if (pos > 0) {
+            int next = t->state.shared_data->tokens[pos];                          // :473
+            if (next >= t->config.vocab_size) next = 0;                            // :474
+            if (next == 2) break;                                                  // eos_token, :477
+        }
+        pos++;
+    }
+    hipStreamSynchronize(g_stream);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    const int timed_tokens = pos - 1;                                              // :488
+    if (out_tokens) {
+        const int n = (pos < steps ? pos : steps) + 1;
+        for (int i = 0; i < n && i < Q4_MAX_SEQ_LEN; i++) out_tokens[i] = t->state.shared_data->tokens[i];
+    }
+    if (timed_tokens_out) *timed_tokens_out = timed_tokens;
+    if (seconds_out) *seconds_out = secs;
+    (void)time_in_ms;
+    return secs > 0 ? timed_tokens / secs : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// perplexity.h:3-51 (host math)
+void q4_softmax_f32(float* x, int size) {
+    float max_val = x[0];
+    for (int i = 1; i < size; i++)
+        if (x[i] > max_val) max_val = x[i];
+    float sum = 0.0f;
+    for (int i = 0; i < size; i++) {
+        x[i] = expf(x[i] - max_val);
+        sum += x[i];
+    }
+    for (int i = 0; i < size; i++) x[i] /= sum;
+}
+float compute_perplexity(const int* tokens, float* logits, int num_tokens, int vocab_size) {
+    double sum = 0.0;
+    for (int i = 0; i < num_tokens; i++) {
+        int word_index = tokens[i];
+        q4_softmax_f32(&logits[(size_t)i * vocab_size], vocab_size);
+        double prob = logits[(size_t)i * vocab_size + word_index];
+        sum += log(prob);
+    }
+    double avg_log_prob = sum / num_tokens;
+    return float(exp(-avg_log_prob));
+}
+
+// get_dataset_perplexity perplexity.h:57-97 on token ids: tokens_with_bos[0] = BOS, targets follow.
+float q4_perplexity_ids(Transformer* t, Sampler* sampler, const int* tokens_with_bos, int num_tokens) {
+    Config* config = &t->config;
+    RunState* state = &t->state;
+    if (!state->logits_array || num_tokens < 1) return -1.0f;
+    if (num_tokens >= config->seq_len) num_tokens = config->seq_len - 1;           // :68-72
+    if (q4_reset_sequence(state, tokens_with_bos, num_tokens + 1)) return -1.0f;   // :76-78
+    for (int pos = 0; pos < num_tokens; pos++) {
+        if (q4_run_transformer(0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
+        if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                    // :81
+    }
+    float* logits_arr = (float*)malloc((size_t)num_tokens * config->vocab_size * sizeof(float));
+    if (q4_get_logits_array(t, num_tokens, logits_arr)) { free(logits_arr); return -1.0f; }   // :88-89
+    float pplx = compute_perplexity(tokens_with_bos + 1, logits_arr, num_tokens, config->vocab_size);   // :91
+    free(logits_arr);
+    return pplx;
+}
+
+}  // extern "C"

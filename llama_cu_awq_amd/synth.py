@@ -1,0 +1,134 @@
+"""Seeded synthetic llama2_q4 checkpoints in the reference's exact `.bin` layout.
+
+No real AWQ weights are available offline, so every bench/parity config runs on synthetic
+weights in the real geometry.  Layout written here == what the reference
+loader reads (llama2_q4.cu:172-202, sizes :82-98) == what weight_packer.cpp:256-291 writes:
+
+    Config header (8 x 4 B)                                   common.h:9-18
+    token_embedding_table [vocab, dim] fp16                   llama2_q4.cu:180
+    wcls                  [vocab, dim] fp16                   :181
+    rms_final_weight      [dim] fp16                          :182
+    per layer: q, k, v, o, up, gate, down  (each: weight u32, zeros u32, scales fp16)   :186-193
+               rms_att_weight [dim], rms_ffn_weight [dim]     :195-196
+
+QWeight (common.h:20-24): column-major per output n; weight[n*K/8 + k/8] nibble k%8 (LSB first),
+zeros[n*pzh + g/8] nibble g%8 (g = k/128), scales[n*G + g].
+
+Distributions: weight/zeros nibbles iid uniform{0..15} (padding nibbles of `zeros` are random
+garbage on purpose, like the reference packer's); scales U[0.002,0.004]; rms weights
+1 +- 0.1; embedding N(0,1); wcls N(0,0.02) with row 2 (EOS) zeroed so greedy runs never stop early.
+"""
+import os
+import struct
+
+import numpy as np
+
+GROUP_SIZE = 128
+
+GEOMETRIES = {
+    # name: (dim, hidden, layers, heads, kv_heads, vocab, seq_len, rope_theta)
+    "7b": (4096, 11008, 32, 32, 32, 32000, 2048, 10000.0),
+    "13b": (5120, 13824, 40, 40, 40, 32000, 2048, 10000.0),
+    "tiny": (256, 352, 2, 4, 4, 512, 64, 10000.0),
+    "tiny_gqa": (256, 352, 2, 8, 2, 512, 64, 10000.0),
+    "small": (512, 1408, 3, 8, 8, 1024, 320, 10000.0),
+}
+
+
+def div_up(a, b):
+    return (a - 1) // b + 1
+
+
+def qweight_sizes(height, width):
+    """(weight_u32, zeros_u32, scales_f16) element counts, llama2_q4.cu:82-98."""
+    pwh = div_up(height, 32) * 4
+    sh = div_up(height, GROUP_SIZE)
+    pzh = div_up(sh, 8)
+    return pwh * width, pzh * width, sh * width
+
+
+def model_bytes(cfg):
+    dim, hidden, layers, heads, kv_heads, vocab, _, _ = cfg
+    kv_dim = dim * kv_heads // heads
+    total = 32 + 2 * vocab * dim * 2 + dim * 2
+    per = 0
+    for (h, w) in ((dim, dim), (dim, kv_dim), (dim, kv_dim), (dim, dim), (dim, hidden), (dim, hidden), (hidden, dim)):
+        a, b, c = qweight_sizes(h, w)
+        per += a * 4 + b * 4 + c * 2
+    per += 2 * dim * 2
+    return total + layers * per
+
+
+def _u32(rng, n):
+    return np.frombuffer(rng.bytes(4 * n), dtype=np.uint32)
+
+
+def _write_qweight(f, rng, height, width, scale_lo, scale_hi):
+    a, b, c = qweight_sizes(height, width)
+    f.write(_u32(rng, a).tobytes())
+    f.write(_u32(rng, b).tobytes())
+    f.write(rng.uniform(scale_lo, scale_hi, c).astype(np.float16).tobytes())
+
+
+def write_model(path, cfg, seed=20240229, scale_lo=0.002, scale_hi=0.004, eos_row_zero=True):
+    """Write a synthetic checkpoint; returns the byte size. One RNG stream per tensor group."""
+    if isinstance(cfg, str):
+        cfg = GEOMETRIES[cfg]
+    dim, hidden, layers, heads, kv_heads, vocab, seq_len, theta = cfg
+    assert dim % 32 == 0 and hidden % 32 == 0, "packed height must be a multiple of 32 (SURVEY P6)"
+    kv_dim = dim * kv_heads // heads
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(struct.pack("<7if", dim, hidden, layers, heads, kv_heads, vocab, seq_len, theta))
+        rng = np.random.Generator(np.random.PCG64(seed))
+        chunk = 1 << 22
+        n = vocab * dim
+        for off in range(0, n, chunk):  # embedding N(0,1)
+            f.write(rng.standard_normal(min(chunk, n - off), dtype=np.float32).astype(np.float16).tobytes())
+        wcls = (rng.standard_normal(n, dtype=np.float32) * 0.02).astype(np.float16).reshape(vocab, dim)
+        if eos_row_zero and vocab > 2:
+            wcls[2, :] = 0
+        f.write(wcls.tobytes())
+        del wcls
+        f.write((1.0 + 0.1 * rng.uniform(-1, 1, dim)).astype(np.float16).tobytes())
+        for l in range(layers):
+            lr = np.random.Generator(np.random.PCG64([seed, l + 1]))
+            _write_qweight(f, lr, dim, dim, scale_lo, scale_hi)      # q
+            _write_qweight(f, lr, dim, kv_dim, scale_lo, scale_hi)   # k
+            _write_qweight(f, lr, dim, kv_dim, scale_lo, scale_hi)   # v
+            _write_qweight(f, lr, dim, dim, scale_lo, scale_hi)      # o
+            _write_qweight(f, lr, dim, hidden, scale_lo, scale_hi)   # up   (before gate, P5)
+            _write_qweight(f, lr, dim, hidden, scale_lo, scale_hi)   # gate
+            _write_qweight(f, lr, hidden, dim, scale_lo, scale_hi)   # down
+            f.write((1.0 + 0.1 * lr.uniform(-1, 1, dim)).astype(np.float16).tobytes())
+            f.write((1.0 + 0.1 * lr.uniform(-1, 1, dim)).astype(np.float16).tobytes())
+        size = f.tell()
+    assert size == model_bytes(cfg), (size, model_bytes(cfg))
+    os.replace(tmp, path)
+    return size
+
+
+def random_qweight(rng, height, width, scale_lo=0.002, scale_hi=0.004):
+    """(weight u32[a], zeros u32[b], scales f16[c]) numpy arrays for kernel-level tests."""
+    a, b, c = qweight_sizes(height, width)
+    return (_u32(rng, a).copy(), _u32(rng, b).copy(), rng.uniform(scale_lo, scale_hi, c).astype(np.float16))
+
+
+def dequant_dense(weight, zeros, scales, height, width):
+    """fp64 dense [width, height] matrix from packed tensors (test helper, analytic check)."""
+    pwh = div_up(height, 32) * 4
+    sh = div_up(height, GROUP_SIZE)
+    pzh = div_up(sh, 8)
+    w = weight.reshape(width, pwh)
+    k = np.arange(height)
+    q = (w[:, k // 8] >> (4 * (k % 8)).astype(np.uint32)) & 0xF
+    g = k // GROUP_SIZE
+    z = (zeros.reshape(width, pzh)[:, g // 8] >> (4 * (g % 8)).astype(np.uint32)) & 0xF
+    s = scales.reshape(width, sh)[:, g].astype(np.float64)
+    return (q.astype(np.float64) - z.astype(np.float64)) * s
+
+
+if __name__ == "__main__":
+    import sys
+    name, out = sys.argv[1], sys.argv[2]
+    print(write_model(out, GEOMETRIES[name]), "bytes ->", out)

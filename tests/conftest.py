@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def q4():
+    """The HIP library with a stream set (GPU tests only). Fails loudly if the .so is missing."""
+    from llama_cu_awq_amd import api
+    import ctypes as C
+    L = api.lib()
+    api.check(L.q4_set_device(0))
+    s = C.c_void_p()
+    api.check(L.q4_stream_create(C.byref(s)))
+    L.q4_set_stream(s)
+    yield api
+    L.q4_stream_synchronize()
+    L.q4_reset_graphs()
+    L.q4_set_stream(None)
+    L.q4_stream_destroy(s)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture()
+def rng():
+    return np.random.default_rng(1234)
+
+
+def f16_ulp_diff(a, b):
+    """Distance in fp16 ulps between two float16 arrays (finite values)."""
+    def key(x):
+        u = np.ascontiguousarray(x, dtype=np.float16).view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
+    return np.abs(key(a) - key(b))
+
+
+def assert_close_f16(gpu, ref16, ref64=None, max_ulp=1, max_frac=0.03, what=""):
+    """GPU fp16 vs the oracle's fp16 (<= max_ulp everywhere, mostly identical) and, when given, vs fp64
+    (|err| <= 1.5 fp16 ulp of the reference + a small absolute slack for cancellation)."""
+    gpu = np.asarray(gpu, dtype=np.float16)
+    assert np.isfinite(gpu.astype(np.float32)).all(), what + ": non-finite output"
+    d = f16_ulp_diff(gpu, ref16)
+    assert d.max() <= max_ulp, "%s: max fp16 ulp diff %d at %d (gpu %r ref %r)" % (
+        what, d.max(), d.argmax(), gpu[d.argmax()], ref16[d.argmax()])
+    assert (d > 0).mean() <= max_frac, "%s: %.3f of outputs differ from the oracle" % (what, (d > 0).mean())
+    if ref64 is not None:
+        err = np.abs(gpu.astype(np.float64) - ref64)
+        tol = 1.5 * np.abs(ref64) * 2.0 ** -10 + 1e-4 * max(1e-6, np.abs(ref64).max()) + 6e-8
+        assert (err <= tol).all(), "%s: vs fp64 worst err %g (tol %g)" % (what, err.max(), tol[err.argmax()])

@@ -1,0 +1,116 @@
+"""End-to-end parity: build_transformer + run_transformer (graphs, fused and 1:1 kernel sequences) against the CPU
+restatement of run_llama_network on synthetic checkpoints (tiny / GQA / small), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from llama_cu_awq_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def models(tmp_path_factory):
+    d = tmp_path_factory.mktemp("models")
+    out = {}
+    for name in ("tiny", "tiny_gqa", "small"):
+        p = str(d / (name + ".bin"))
+        synth.write_model(p, name, seed=7)
+        out[name] = p
+    return out
+
+
+def _logit_close(gpu, ref):
+    gpu, ref = gpu.astype(np.float64), ref.astype(np.float64)
+    return np.abs(gpu - ref) <= 3e-2 * np.maximum(1.0, np.abs(ref))    # SURVEY 8c forward tolerance
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small"])
+@pytest.mark.parametrize("fusion,graphs", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
+    L = q4.lib()
+    L.q4_set_fusion(fusion)
+    L.q4_set_use_graphs(graphs)
+    try:
+        t = q4.Transformer(models[name])
+        m = orc.Model(models[name])
+        prompt = [1, 17, 300, 45, 9]
+        steps = 12
+        t.reset(prompt)
+        toks = list(prompt)
+        for pos in range(steps):
+            gen = pos >= len(prompt) - 1
+            t.run_transformer(gen)
+            q4.synchronize()
+            ref = m.forward(toks[pos], pos)
+            got = t.logits()
+            assert _logit_close(got, ref).all(), "pos %d: max |d| %g" % (pos, np.abs(got.astype(np.float32) - ref.astype(np.float32)).max())
+            assert t.pos() == pos + 1
+            if gen:
+                nxt = t.token(pos + 1)
+                top2 = np.sort(ref.astype(np.float32))[-2:]
+                if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):      # not a near-tie
+                    assert nxt == int(np.argmax(ref.astype(np.float32))), pos
+                toks.append(nxt)
+        rk, rv = m.kv()
+        for layer in range(t.config.n_layers):
+            for pos in (0, steps - 1):
+                gk, gv = t.kv_row(layer, pos)
+                assert _logit_close(gk, rk[layer, pos]).all() and _logit_close(gv, rv[layer, pos]).all(), (layer, pos)
+        t.close()
+        m.close()
+    finally:
+        L.q4_set_fusion(1)
+        L.q4_set_use_graphs(1)
+
+
+def test_fused_equals_unfused_bits(q4, models):
+    """The fused sequence must reproduce the 1:1 kernel chain (same canonical reductions): identical logits."""
+    L = q4.lib()
+    outs = []
+    for fusion in (0, 1):
+        L.q4_set_fusion(fusion)
+        t = q4.Transformer(models["small"])
+        t.reset([1, 5, 9])
+        for pos in range(6):
+            t.run_transformer(pos >= 2)
+        q4.synchronize()
+        outs.append(t.logits().copy())
+        t.close()
+    L.q4_set_fusion(1)
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
+def test_generate_ids_matches_oracle(q4, orc, models):
+    t = q4.Transformer(models["small"])
+    m = orc.Model(models["small"])
+    prompt = [1, 400, 22, 7, 513, 99, 1000, 3]
+    steps = 48
+    gtoks, tps, timed, secs = t.generate_ids(prompt, steps)
+    rtoks, rlogits = m.generate_greedy(prompt, steps, want_logits=True)
+    assert timed == steps - 1 and tps > 0
+    # identical until the first near-tie in the oracle's logits
+    n = min(len(gtoks), len(rtoks))
+    for i in range(n):
+        if gtoks[i] != rtoks[i]:
+            lg = np.sort(rlogits[i - 1])[-2:]
+            assert lg[1] - lg[0] < 4e-3 * max(1.0, abs(lg[1])), "token %d differs without a near-tie" % i
+            break
+    t.close()
+    m.close()
+
+
+def test_perplexity_path(q4, orc, models):
+    t = q4.Transformer(models["small"], perplexity=True)
+    m = orc.Model(models["small"])
+    rng = np.random.default_rng(3)
+    toks = np.concatenate([[1], rng.integers(3, 1024, size=40)]).astype(np.int32)
+    ppl = t.perplexity_ids(toks)
+    glog = t.logits_array(40)
+    rlog = np.stack([m.forward(int(toks[i]), i).astype(np.float32) for i in range(40)])
+    assert (np.abs(glog - rlog) <= 3e-2 * np.maximum(1.0, np.abs(rlog))).all()
+    rppl = orc.compute_perplexity(toks[1:41], rlog)
+    assert abs(ppl - rppl) <= 5e-3 * rppl, (ppl, rppl)      # perplexity within 0.5 %
+    t.close()
+    m.close()

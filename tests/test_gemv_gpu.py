@@ -1,0 +1,121 @@
+"""Parity of the int4 GEMV family (mat_vec_kernel_int4 / qkv_matvec_kernel / ffn_matvec_silu_kernel,
+gpu_kernels.h:171-275) against the CPU restatement, through the C ABI. Tolerance: <= 1 fp16 ulp vs the
+oracle's lane-order fp32 result, and <= 1.5 fp16 ulp (+1e-4*max) vs an fp64 dense evaluation."""
+import numpy as np
+import pytest
+
+from conftest import assert_close_f16
+from llama_cu_awq_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 5120), (5120, 13824), (13824, 5120),
+          (256, 352), (352, 256), (2048, 64), (8192, 1024), (16384, 256), (32, 8)]
+
+
+def _mk(rng, K, N):
+    w, z, s = synth.random_qweight(rng, K, N)
+    x = rng.standard_normal(K).astype(np.float16)
+    return w, z, s, x
+
+
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_matmul_q4_plain(q4, orc, rng, K, N):
+    w, z, s, x = _mk(rng, K, N)
+    ref16 = orc.matmul_q4(x, w, z, s, K, N)
+    ref64 = orc.matmul_q4_f64(x, w, z, s, K, N)
+    dw = q4.DevQWeight(w, z, s)
+    dx, dout = q4.DevBuf(x), q4.DevBuf(nbytes=N * 2)
+    q4.matmul_q4(dout, dx, dw, K, N)
+    q4.synchronize()
+    assert_close_f16(dout.get(np.float16, N), ref16, ref64, what="plain %dx%d" % (K, N))
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (352, 256)])
+def test_matmul_q4_accum(q4, orc, rng, K, N):
+    w, z, s, x = _mk(rng, K, N)
+    old = rng.standard_normal(N).astype(np.float16)
+    ref16 = orc.matmul_q4(x, w, z, s, K, N, accum_into=old)
+    dw = q4.DevQWeight(w, z, s)
+    dx, dout = q4.DevBuf(x), q4.DevBuf(old)
+    q4.matmul_q4(dout, dx, dw, K, N, accum=True)
+    q4.synchronize()
+    assert_close_f16(dout.get(np.float16, N), ref16, what="accum %dx%d" % (K, N))
+
+
+def test_matmul_q4_kv_addressing(q4, orc, rng):
+    K, N, seq, pos, layer = 256, 256, 8, 5, 1
+    w, z, s, x = _mk(rng, K, N)
+    loff = layer * seq * N
+    cache = np.zeros(2 * seq * N, dtype=np.float16)
+    ref = cache.copy()
+    orc.matmul_q4(x, w, z, s, K, N, loff=loff, pos=pos, out=ref)
+    dw = q4.DevQWeight(w, z, s)
+    dx, dc, dpos = q4.DevBuf(x), q4.DevBuf(cache), q4.DevBuf(np.array([pos], dtype=np.int32))
+    q4.matmul_q4(dc, dx, dw, K, N, loff=loff, pPos=dpos)
+    q4.synchronize()
+    got = dc.get(np.float16)
+    assert_close_f16(got, ref, what="kv addressing")
+    assert (got[: loff + pos * N] == 0).all() and (got[loff + (pos + 1) * N:] == 0).all()
+
+
+@pytest.mark.parametrize("K,N", [(4096, 11008), (5120, 13824), (256, 352)])
+def test_ffn_matvec_silu(q4, orc, rng, K, N):
+    g = synth.random_qweight(rng, K, N)
+    u = synth.random_qweight(rng, K, N)
+    x = rng.standard_normal(K).astype(np.float16)
+    ref16 = orc.ffn_matvec_silu(x, g, u, K, N)
+    dg, du = q4.DevQWeight(*g), q4.DevQWeight(*u)
+    dx, dout = q4.DevBuf(x), q4.DevBuf(nbytes=N * 2)
+    q4.ffn_matvec_silu(dout, dx, dg, du, K, N)
+    q4.synchronize()
+    # silu(g)*u multiplies two rounded sums: allow 2 ulp
+    assert_close_f16(dout.get(np.float16, N), ref16, max_ulp=2, max_frac=0.06, what="ffn %dx%d" % (K, N))
+
+
+@pytest.mark.parametrize("dim", [4096, 256])
+def test_qkv_matvec(q4, orc, rng, dim):
+    seq, pos, layer = 6, 3, 1
+    mats = [synth.random_qweight(rng, dim, dim) for _ in range(3)]
+    x = rng.standard_normal(dim).astype(np.float16)
+    loff = layer * seq * dim
+    kc = np.zeros(2 * seq * dim, dtype=np.float16)
+    vc = kc.copy()
+    rq = orc.matmul_q4(x, *mats[0], dim, dim)
+    rk, rv = kc.copy(), vc.copy()
+    orc.matmul_q4(x, *mats[1], dim, dim, loff=loff, pos=pos, out=rk)
+    orc.matmul_q4(x, *mats[2], dim, dim, loff=loff, pos=pos, out=rv)
+    dm = [q4.DevQWeight(*m) for m in mats]
+    dx, dq, dk, dv = q4.DevBuf(x), q4.DevBuf(nbytes=dim * 2), q4.DevBuf(kc), q4.DevBuf(vc)
+    dpos = q4.DevBuf(np.array([pos], dtype=np.int32))
+    q4.qkv_matvec(dq, dk, dv, dx, dm[0], dm[1], dm[2], dim, dim, loff, dpos)
+    q4.synchronize()
+    assert_close_f16(dq.get(np.float16, dim), rq, what="q")
+    assert_close_f16(dk.get(np.float16), rk, what="k cache")
+    assert_close_f16(dv.get(np.float16), rv, what="v cache")
+
+
+def test_unsupported_sizes(q4, rng):
+    """(n&7)||(d&7) -> "Unsupported matmul size" (llama2_q4.cu:225), reported as a status code."""
+    w, z, s = synth.random_qweight(rng, 64, 16)
+    dw = q4.DevQWeight(w, z, s)
+    dx, dout = q4.DevBuf(nbytes=256), q4.DevBuf(nbytes=256)
+    with pytest.raises(q4.Q4Error, match="Unsupported matmul size"):
+        q4.matmul_q4(dout, dx, dw, 64, 12)
+    with pytest.raises(q4.Q4Error, match="Unsupported matmul size"):
+        q4.matmul_q4(dout, dx, dw, 60, 16)
+
+
+def test_linearity_full_size(q4, rng):
+    """Size-independent property at the BASELINE shape: GEMV(a*x) == a*GEMV(x) for a power of two,
+    and columns are independent (permuting column blocks permutes outputs)."""
+    K, N = 4096, 11008
+    w, z, s = synth.random_qweight(rng, K, N)
+    x = (rng.standard_normal(K) * 0.5).astype(np.float16)
+    dw = q4.DevQWeight(w, z, s)
+    o1, o2 = q4.DevBuf(nbytes=N * 2), q4.DevBuf(nbytes=N * 2)
+    q4.matmul_q4(o1, q4.DevBuf(x), dw, K, N)
+    q4.matmul_q4(o2, q4.DevBuf((x * np.float16(2)).astype(np.float16)), dw, K, N)
+    q4.synchronize()
+    a, b = o1.get(np.float16, N).astype(np.float32), o2.get(np.float16, N).astype(np.float32)
+    assert np.array_equal(a * 2, b)

@@ -1,0 +1,109 @@
+"""Parity of the fp16 companion kernels (rmsnorm, fp16 GEMV, RoPE, attention, embedding, argmax, fp16->fp32)
+against the CPU restatement, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import assert_close_f16, f16_ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("size", [4096, 5120, 256, 8])
+def test_rmsnorm(q4, orc, rng, size):
+    x = (rng.standard_normal(size) * 3).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(size)).astype(np.float16)
+    ref = orc.rmsnorm(x, w)
+    dx, dw, do = q4.DevBuf(x), q4.DevBuf(w), q4.DevBuf(nbytes=size * 2)
+    q4.rmsnorm(do, dx, dw, size)
+    q4.synchronize()
+    assert_close_f16(do.get(np.float16, size), ref, what="rmsnorm")
+    q4.rmsnorm(dx, dx, dw, size)        # in place, as the final norm (llama2_q4.cu:336)
+    q4.synchronize()
+    assert_close_f16(dx.get(np.float16, size), ref, what="rmsnorm in place")
+
+
+@pytest.mark.parametrize("n,d", [(4096, 32000), (5120, 1000), (256, 512), (2048, 64)])
+def test_matmul_f16(q4, orc, rng, n, d):
+    w = (rng.standard_normal(n * d) * 0.02).astype(np.float16)
+    x = rng.standard_normal(n).astype(np.float16)
+    ref = orc.matmul_f16(x, w, n, d)
+    ref64 = w.reshape(d, n).astype(np.float64) @ x.astype(np.float64)
+    dw, dx, do = q4.DevBuf(w), q4.DevBuf(x), q4.DevBuf(nbytes=d * 2)
+    q4.matmul(do, dx, dw, n, d)
+    q4.synchronize()
+    assert_close_f16(do.get(np.float16, d), ref, ref64, what="fp16 gemv %dx%d" % (n, d))
+
+
+@pytest.mark.parametrize("heads,kv_heads,hs,pos", [(32, 32, 128, 0), (32, 32, 128, 255), (8, 2, 64, 17), (4, 4, 64, 2047)])
+def test_rope(q4, orc, rng, heads, kv_heads, hs, pos):
+    q = rng.standard_normal(heads * hs).astype(np.float16)
+    seq = pos + 2
+    kv_dim = kv_heads * hs
+    kc = rng.standard_normal(2 * seq * kv_dim).astype(np.float16)
+    loff = seq * kv_dim
+    krow = kc[loff + pos * kv_dim: loff + (pos + 1) * kv_dim]
+    rq, rk = orc.rope(q, krow, heads, kv_heads, hs, pos, 10000.0)
+    dq, dk, dpos = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(np.array([pos], dtype=np.int32))
+    q4.RoPERotation(dq, dk, heads, kv_heads, hs, dpos, loff, 10000.0)
+    q4.synchronize()
+    gk = dk.get(np.float16)
+    # device sinf/cosf/powf vs glibc: a few fp32 ulp on angles up to 2047 rad -> at most 1 fp16 ulp after rounding
+    assert_close_f16(dq.get(np.float16), rq, max_frac=0.05, what="rope q")
+    assert_close_f16(gk[loff + pos * kv_dim: loff + (pos + 1) * kv_dim], rk, max_frac=0.05, what="rope k")
+    untouched = np.ones(gk.shape[0], dtype=bool)
+    untouched[loff + pos * kv_dim: loff + (pos + 1) * kv_dim] = False
+    assert np.array_equal(gk[untouched], kc[untouched])
+
+
+@pytest.mark.parametrize("heads,kv_mul,hs,pos,seq", [(32, 1, 128, 0, 128), (32, 1, 128, 255, 256), (32, 1, 128, 300, 512),
+                                                      (8, 4, 64, 40, 128), (4, 1, 64, 63, 64), (4, 2, 256, 9, 128),
+                                                      (8, 1, 32, 20, 128), (32, 1, 128, 2047, 2048)])
+def test_attention(q4, orc, rng, heads, kv_mul, hs, pos, seq):
+    dim = heads * hs
+    kv_dim = dim // kv_mul
+    q = rng.standard_normal(dim).astype(np.float16)
+    kc = rng.standard_normal(seq * kv_dim).astype(np.float16)
+    vc = rng.standard_normal(seq * kv_dim).astype(np.float16)
+    ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos)
+    dq, dk, dv, do = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(vc), q4.DevBuf(nbytes=dim * 2)
+    dpos = q4.DevBuf(np.array([pos], dtype=np.int32))
+    q4.MultiHeadAttention(do, dq, dk, dv, None, heads, hs, kv_mul, seq, dpos)
+    q4.synchronize()
+    got = do.get(np.float16, dim)
+    # expf ulps + summation order on fp16-rounded probabilities: allow 2 fp16 ulp, small fraction
+    d = f16_ulp_diff(got, ref)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), (d.max(), err.max())
+    assert (d > 2).mean() < 0.02, (d > 2).mean()
+
+
+def test_copy_embedding_and_convert(q4, rng):
+    size, vocab = 4096, 64
+    table = rng.standard_normal(vocab * size).astype(np.float16)
+    tokens = np.array([3, 7, 42, 1], dtype=np.int32)
+    dt, dx = q4.DevBuf(table), q4.DevBuf(nbytes=size * 2)
+    dtok, dpos = q4.DevBuf(tokens), q4.DevBuf(np.array([2], dtype=np.int32))
+    q4.check(q4.lib().q4_copy_embedding(dx.ptr, dt.ptr, size, dtok.ptr, dpos.ptr))
+    q4.synchronize()
+    assert np.array_equal(dx.get(np.float16, size), table[42 * size: 43 * size])
+    df = q4.DevBuf(nbytes=size * 4)
+    q4.check(q4.lib().q4_convert_fp16_to_fp32(df.ptr, dx.ptr, size))
+    q4.synchronize()
+    assert np.array_equal(df.get(np.float32, size), table[42 * size: 43 * size].astype(np.float32))
+
+
+@pytest.mark.parametrize("size", [32000, 512, 1000])
+def test_argmax(q4, orc, rng, size):
+    x = rng.standard_normal(size).astype(np.float16)
+    x[[5, size - 3]] = x.max() + np.float16(1)     # a tie: lowest index must win
+    dx = q4.DevBuf(x)
+    ring = q4.DevBuf(np.zeros(16, dtype=np.int32))
+    hpos, dpos = q4.DevBuf(np.array([4], dtype=np.int32)), q4.DevBuf(np.array([0], dtype=np.int32))
+    q4.check(q4.lib().q4_argmax(dx.ptr, size, ring.ptr, hpos.ptr, dpos.ptr, 1))
+    q4.synchronize()
+    assert orc.argmax(x) == 5
+    r = ring.get(np.int32)
+    assert r[5] == 5 and hpos.get(np.int32)[0] == 5 and dpos.get(np.int32)[0] == 5
+    q4.check(q4.lib().q4_argmax(dx.ptr, size, ring.ptr, hpos.ptr, dpos.ptr, 0))   # prompt phase: only advance pos
+    q4.synchronize()
+    assert ring.get(np.int32)[6] == 0 and hpos.get(np.int32)[0] == 6
