@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--force-dist", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,6 +74,8 @@ def main():
     from llama_cu_awq_amd import api, synth   # raises if libllama2_q4.so is missing: no fallback
     L = api.lib()
     api.check(L.q4_set_device(local_rank if world > 1 else 0))
+    if args.no_graphs:
+        L.q4_set_use_graphs(0)
 
     dist = None
     if use_dist:

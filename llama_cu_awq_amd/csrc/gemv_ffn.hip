@@ -5,13 +5,16 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves) {
 #define Q4_CASE(S, C) if (slots == S && cols == C) { \
         return a.rms_w ? launch_one<MODE_FFN, S, C, true>(a, waves) : launch_one<MODE_FFN, S, C, false>(a, waves); }
     const int slots = pick_slots(a.nslots);
-    if (cols != 1 && cols != 2 && cols != 4) cols = 2;
-    if (slots >= 3 && cols == 4) cols = 2;   // gate+up doubles the loads in flight
-    if (slots >= 6 && cols == 2) cols = 1;
-    Q4_CASE(2, 1) Q4_CASE(2, 2) Q4_CASE(2, 4)
-    Q4_CASE(3, 1) Q4_CASE(3, 2)
-    Q4_CASE(4, 1) Q4_CASE(4, 2)
-    Q4_CASE(6, 1) Q4_CASE(7, 1) Q4_CASE(8, 1)
+    if (g_ablate && slots == 2 && a.rms_w) {   // profiling-only ablations of the 7B gate/up kernel
+        if (g_ablate == 1) return launch_one<MODE_FFN, 2, 2, true, 1>(a, waves);
+        if (g_ablate == 2) return launch_one<MODE_FFN, 2, 2, true, 2>(a, waves);
+        if (g_ablate == 3) return launch_one<MODE_FFN, 2, 2, true, 3>(a, waves);
+    }
+    if (cols != 2 && cols != 4) cols = 2;
+    if (slots >= 4 && cols == 4) cols = 2;   // gate+up doubles the loads in flight
+    Q4_CASE(2, 2) Q4_CASE(2, 4)
+    Q4_CASE(3, 2) Q4_CASE(3, 4)
+    Q4_CASE(4, 2) Q4_CASE(6, 2) Q4_CASE(7, 2) Q4_CASE(8, 2)
 #undef Q4_CASE
     return Q4_ERR_UNSUPPORTED_SIZE;
 }

@@ -4,14 +4,11 @@ namespace q4 {
 int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
 #define Q4_CASE(S, C) if (slots == S && cols == C) return launch_one<MODE_PLAIN, S, C, false>(a, waves);
     const int slots = pick_slots(a.nslots);
-    if (cols != 1 && cols != 2 && cols != 4) cols = 2;
-    if (slots >= 6 && cols == 4) cols = 2;   // 6x4 uint4 per lane does not fit the register file
-    Q4_CASE(2, 1) Q4_CASE(2, 2) Q4_CASE(2, 4)
-    Q4_CASE(3, 1) Q4_CASE(3, 2) Q4_CASE(3, 4)
-    Q4_CASE(4, 1) Q4_CASE(4, 2) Q4_CASE(4, 4)
-    Q4_CASE(6, 1) Q4_CASE(6, 2)
-    Q4_CASE(7, 1) Q4_CASE(7, 2)
-    Q4_CASE(8, 1) Q4_CASE(8, 2)
+    if (cols != 4 && cols != 8) cols = 4;
+    if (slots >= 4 && cols == 8) cols = 4;   // 8 columns x >= 4 uint4 per lane does not fit the register file
+    Q4_CASE(2, 4) Q4_CASE(2, 8)
+    Q4_CASE(3, 4) Q4_CASE(3, 8)
+    Q4_CASE(4, 4) Q4_CASE(6, 4) Q4_CASE(7, 4) Q4_CASE(8, 4)
 #undef Q4_CASE
     return Q4_ERR_UNSUPPORTED_SIZE;
 }

@@ -1,24 +1,29 @@
-// gemv_q4.h -- the INT4-AWQ dequant-fused GEMV for gfx950 (wave64), all three launch shapes of the
+// gemv_q4.h -- the INT4-AWQ dequant-fused GEMV for gfx950 (wave64). All three launch shapes of the
 // reference share this one kernel template:
 //   MODE_PLAIN : mat_vec_kernel_int4      gpu_kernels.h:213-240  (accum / KV addressing)
 //   MODE_QKV   : qkv_matvec_kernel        gpu_kernels.h:242-254  (+ optional RoPE epilogue :332-355)
 //   MODE_FFN   : ffn_matvec_silu_kernel   gpu_kernels.h:256-275
-// and optionally fold rmsnorm (gpu_kernels.h:72-105) into the activation staging.
+// and can fold rmsnorm (gpu_kernels.h:72-105) into the activation staging.
 //
 // Mapping (designed from the data layout, SURVEY a1, not from the reference's 32x4 blocks):
-//  * a column n is a contiguous run of K/32 uint4 (32 nibbles each). One WAVE owns COLS columns; lane l
-//    reads uint4 j = slot*64 + l of each of them with one 128-bit non-temporal load -> a wave instruction
-//    moves 1 KiB of one column, fully coalesced. All SLOTS x COLS (x 2 for gate/up) loads of a wave are
-//    issued before anything is consumed, so the whole matrix is in flight at once (q/k/v/o are only
-//    ~32 KiB per CU: one HBM round trip, no second wave of requests).
-//  * the activation vector is staged once per block into LDS, pre-permuted so that the 16 B a lane needs
-//    for weight dword d are one conflict-free ds_read_b128: unit [(slot*4 + d)*64 + lane] holds
-//    (x0,x4),(x1,x5),(x2,x6),(x3,x7) of the 8 inputs that dword multiplies.
-//  * dequant without int->float converts: (w & 0x000F000F) | 0x64006400 is the half2 (1024+q_i, 1024+q_{i+4});
-//    v_pk_add_f16 with -(1024+z) gives the exact (q-z) pair; the odd nibbles sit 4 bits higher, i.e.
-//    (1024+16q), and v_pk_fma_f16 by 1/16 with -(64+z) gives exact (q-z) again. v_dot2c_f32_f16 then
-//    accumulates (q-z)*x in fp32; the group scale is applied once per 32 weights. 13 VALU per 8 weights.
-//  * wave reduction by DPP row ops + 4 v_readlane (no LDS, no cub).
+//  * a column n is a contiguous run of K/32 uint4 (32 nibbles each). One WAVE owns COLS columns; lane l reads
+//    uint4 j = slot*64 + l of each with one 128-bit non-temporal buffer load: a wave instruction moves 1 KiB of
+//    one column, fully coalesced; the column offset rides in the SGPR soffset, so loads cost no VALU. Every load
+//    of a wave is issued before anything is consumed: the whole matrix is in flight at once.
+//  * the activation vector is staged once per block into LDS, pre-permuted so that the 16 B a lane needs for
+//    weight dword d are one conflict-free ds_read_b128: unit [(slot*4 + d)*64 + lane] holds (x0,x4),(x1,x5),
+//    (x2,x6),(x3,x7) of the 8 inputs that dword multiplies.
+//  * dequant without converts or subtracts -- the kernel is VALU-bound if written naively (measured: v_and_or,
+//    v_dot2c, v_pk_* all issue at half rate, ~1.8 ns per wave instruction per SIMD):
+//      (w & 0x000F000F) | 0x64006400 is the half2 (1024+q_i, 1024+q_{i+4}); the odd nibbles sit 4 bits higher,
+//      i.e. (1024+16 q). v_dot2c_f32_f16 accumulates them against x in two fp32 accumulators:
+//         acc_e = 1024*Se + sum_even q x        acc_o = 1024*So + 16 * sum_odd q x
+//      and per 32 weights  sum (q-z) x = acc_e + acc_o/16 - (1024 Se + 64 So) - z (Se + So), where the two
+//      x-only terms are computed once per block during staging. 9 VALU per 8 weights instead of 13, fp32 error
+//      ~2^-24 * 1024 * |x| per term (far below one fp16 ulp of the output).
+//  * cross-lane reduction transposes while it reduces (v_permlane32_swap, v_permlane16_swap, DPP row ops):
+//    4 (8) column sums cost 10 (20) VALU instead of 44 (88), and leave column r's total in DPP row r, so the
+//    epilogue (residual add / SiLU / RoPE) runs once for all columns in parallel lanes.
 // No MFMA: 3.84 flop/B, the kernel is an HBM stream.
 #pragma once
 #include "q4_device.h"
@@ -47,33 +52,12 @@ struct GemvArgs {
     int rope;               // QKV: rotate q and k in the epilogue
     int head_size;
     float rope_theta;
+    unsigned long long* dbg;   // ABL == 3 only: per-wave s_memtime stamps
+    const float2* rope_table;  // [seq_len][head_size/2] (cos, sin) built with the reference's formula; null: compute
 };
 
 template <int MODE>
 struct ModeTraits { static constexpr int NMAT = (MODE == MODE_FFN) ? 2 : 1; };
-
-// one 32-weight unit: w = packed nibbles (uint4), xs = 4 permuted activation units, returns sum (q-z)*x
-__device__ __forceinline__ float dot32_q4(u32x4 w, const u32x4 (&X)[4], unsigned z, unsigned M0, unsigned M1,
-                                          unsigned MG) {
-    const h2 cz0 = as_h2(0xE400E400u + z * 0x00010001u);   // -(1024+z) x2
-    const h2 cz1 = as_h2(0xD400D400u + z * 0x00100010u);   // -(64+z)   x2
-    const h2 s16 = {(f16_t)0.0625f, (f16_t)0.0625f};
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const unsigned ww = w[d];
-        const unsigned t = ww >> 8;
-        const h2 q0 = as_h2((ww & M0) | MG) + cz0;            // (n0, n4)
-        const h2 q1 = as_h2((ww & M1) | MG) * s16 + cz1;      // (n1, n5)
-        const h2 q2 = as_h2((t & M0) | MG) + cz0;             // (n2, n6)
-        const h2 q3 = as_h2((t & M1) | MG) * s16 + cz1;       // (n3, n7)
-        acc = __builtin_amdgcn_fdot2(q0, as_h2(X[d][0]), acc, false);
-        acc = __builtin_amdgcn_fdot2(q1, as_h2(X[d][1]), acc, false);
-        acc = __builtin_amdgcn_fdot2(q2, as_h2(X[d][2]), acc, false);
-        acc = __builtin_amdgcn_fdot2(q3, as_h2(X[d][3]), acc, false);
-    }
-    return acc;
-}
 
 // permute 8 consecutive halves (x0..x7 as 4 dwords) into (x0,x4),(x1,x5),(x2,x6),(x3,x7)
 __device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
@@ -85,25 +69,57 @@ __device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
     return o;
 }
 
-template <int MODE, int SLOTS, int COLS, bool NORM>
-__global__ void __launch_bounds__(512) gemv_q4_kernel(const GemvArgs a) {
+// vdst/src half exchange (v_permlane32_swap): returns a' + b' where lanes 0-31 = a[l] + a[l+32],
+// lanes 32-63 = b[l-32] + b[l]. Inline asm on purpose: with __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) folded
+// the two results of the builtin into one register here (emitted v_add v, v14, v14 after `v_permlane32_swap v14, v7`),
+// i.e. 2*a' instead of a' + b'. The s_nop covers the VALU-write -> permlane-read hazard (2 wait states).
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// same at 16-lane granularity (v_permlane16_swap): even rows = a[l] + a[l+16], odd rows = b[l-16] + b[l]
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// 4 per-lane partial sums -> every lane of DPP row r (lanes 16r..16r+15) holds the 64-lane total of v[r]
+__device__ __forceinline__ float reduce4_rows(float v0, float v1, float v2, float v3) {
+    const float u0 = swap32_add(v0, v2);   // lower half: v0, upper half: v2
+    const float u1 = swap32_add(v1, v3);   // lower half: v1, upper half: v3
+    return row16_sum(swap16_add(u0, u1));  // rows: v0, v1, v2, v3
+}
+
+// ABL (profiling-only ablation builds): 0 = product, 1 = loads kept but no dequant math, 2 = math on constants
+// without the weight loads.
+// register-heavy shapes (>= 24 uint4 in flight per lane, e.g. the 7B down projection) run 4 waves per block with
+// the whole 512-register file per lane; the others may use 8 waves per block
+template <int MODE, int SLOTS, int COLS>
+struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
+
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0>
+__global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
+    constexpr int NV = NMAT * COLS;             // column sums per wave
+    static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
     constexpr int NUNITS = SLOTS * 256;         // 16-byte LDS units (zero padded past K)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* xs = reinterpret_cast<u32x4*>(smem);                          // [SLOTS][4][64]
-    float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16);  // [NUNITS] chunk partials + bcast
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                                   // [SLOTS][4][64] permuted x
+    float2* sx = reinterpret_cast<float2*>(smem + (size_t)NUNITS * 16);           // [SLOTS][64] (-(1024Se+64So), -(Se+So))
+    float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16 + SLOTS * 512);   // [NUNITS] chunk partials
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: column bases stay in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: column offsets stay in SGPRs
     const int nw = blockDim.x >> 6;
     const int wg = blockIdx.x * nw + wave;      // global wave index
     const int mat0 = (MODE == MODE_QKV) ? blockIdx.y : 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ABL == 3) ts[0] = __builtin_readcyclecounter();
 
     // ---- column ownership ---------------------------------------------------------------------
     int col[COLS];
     if (MODE == MODE_QKV) {
-        // pairs (i, i + head_size/2) of one head live in the same wave so RoPE needs no exchange
+        // pairs (i, i + head_size/2) of one head live in the same wave so RoPE needs no other wave
         constexpr int P = COLS / 2;
         const int hp = a.head_size >> 1;
 #pragma unroll
@@ -117,12 +133,9 @@ __global__ void __launch_bounds__(512) gemv_q4_kernel(const GemvArgs a) {
 #pragma unroll
         for (int c = 0; c < COLS; c++) col[c] = wg * COLS + c;
     }
-    bool valid[COLS];
+    int colc[COLS];   // clamped: loads stay in bounds, the store is skipped
 #pragma unroll
-    for (int c = 0; c < COLS; c++) {
-        valid[c] = col[c] < a.N;
-        col[c] = valid[c] ? col[c] : a.N - 1;   // clamp: loads stay in bounds, the store is skipped
-    }
+    for (int c = 0; c < COLS; c++) colc[c] = col[c] < a.N ? col[c] : a.N - 1;
 
     // ---- 1. activation loads first: their wait (counted vmcnt) leaves the weight loads in flight ----
     const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
@@ -135,39 +148,43 @@ __global__ void __launch_bounds__(512) gemv_q4_kernel(const GemvArgs a) {
         if (NORM) wraw[i] = reinterpret_cast<const u32x4*>(a.rms_w)[uc];
     }
 
-    float old[COLS];
-    if (MODE == MODE_PLAIN) {
-        const q4_half* ob = a.out[0];
-        if (a.loff != -1) ob += (size_t)a.loff + (size_t)(*a.pPos) * a.N;
-#pragma unroll
-        for (int c = 0; c < COLS; c++) old[c] = a.accum ? h2f(ob[col[c]]) : 0.f;
-    }
-
-    // ---- 2. issue every weight / zero / scale load of this wave ---------------------------------
+    // ---- 2. weight / zero / scale loads: the first PRE slots go out BEFORE the activation staging (so HBM is
+    // busy while the block normalises x), the rest right after it. Measured with s_memtime stamps: issuing every
+    // load first parks a wave ~7000 cycles in VMEM issue back-pressure and only then starts the ~4000-cycle
+    // x -> norm -> LDS chain; staging in the shadow of the first batch removes that chain from the kernel's tail.
+    // Buffer loads: descriptor per tensor (SGPRs), wave-uniform column byte offset in soffset (SGPR), the lane's
+    // offset inside the column in voffset (one VGPR per slot, shared by every column and matrix) -> no per-load
+    // address arithmetic on the VALU. aux = 2 is the non-temporal hint (weights are read once per token).
+    constexpr int PRE = (SLOTS + 1) / 2;
     u32x4 W[NMAT][SLOTS][COLS];
     unsigned ZW[NMAT][SLOTS][COLS];
     uint16_t SC[NMAT][SLOTS][COLS];
-    bool act[SLOTS];
+    __amdgpu_buffer_rsrc_t rw[NMAT], rz[NMAT], rs[NMAT];
 #pragma unroll
-    for (int s = 0; s < SLOTS; s++) {
-        const unsigned j = s * 64 + lane;
-        act[s] = j < (unsigned)a.pw4;
-        const unsigned jj = act[s] ? j : (unsigned)a.pw4 - 1;
-#pragma unroll
-        for (int m = 0; m < NMAT; m++) {
-            const GemvMat& M = a.m[mat0 + m];
-#pragma unroll
-            for (int c = 0; c < COLS; c++) {
-                const uint32_t* zc = M.z + (size_t)col[c] * a.pzh;       // wave-uniform bases
-                const q4_half* sc = M.s + (size_t)col[c] * a.sh;
-                const u32x4* wc = reinterpret_cast<const u32x4*>(M.w) + (size_t)col[c] * a.pw4;
-                ZW[m][s][c] = zc[jj >> 5];
-                SC[m][s][c] = sc[jj >> 2];
-                W[m][s][c] = ld_nt(wc + jj);
-            }
-        }
+    for (int m = 0; m < NMAT; m++) {
+        const GemvMat& M = a.m[mat0 + m];
+        rw[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.w, 0, a.N * a.pw4 * 16, 0x00020000);
+        rz[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.z, 0, a.N * a.pzh * 4, 0x00020000);
+        rs[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.s, 0, a.N * a.sh * 2, 0x00020000);
     }
+#define Q4_ISSUE_SLOT(s)                                                                                          \
+    {                                                                                                             \
+        const unsigned j = (s) * 64 + lane;                                                                       \
+        const unsigned jj = j < (unsigned)a.pw4 ? j : (unsigned)a.pw4 - 1; /* tail lanes re-read the last unit */ \
+        _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c++) {       \
+            ZW[m][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4, colc[c] * a.pzh * 4, 0);     \
+            SC[m][s][c] = __builtin_amdgcn_raw_buffer_load_b16(rs[m], (jj >> 2) * 2, colc[c] * a.sh * 2, 0);      \
+            if (ABL == 2)                                                                                         \
+                W[m][s][c] = (u32x4){jj * 2654435761u, jj ^ 0x9E3779B9u, (unsigned)colc[c] * 40503u, jj + 7u};    \
+            else                                                                                                  \
+                W[m][s][c] = __builtin_amdgcn_raw_buffer_load_b128(rw[m], jj * 16, colc[c] * a.pw4 * 16, 2);      \
+        }                                                                                                         \
+    }
+#pragma unroll
+    for (int s = 0; s < PRE; s++) Q4_ISSUE_SLOT(s)
+    __builtin_amdgcn_sched_barrier(0);
 
+    if (ABL == 3) ts[1] = __builtin_readcyclecounter();
     // ---- 3. stage the activation vector into LDS, optional fused rmsnorm -----------------------
     {
         float ss = 1.f;
@@ -178,19 +195,39 @@ __global__ void __launch_bounds__(512) gemv_q4_kernel(const GemvArgs a) {
                 if (u < NUNITS) part[u] = u < nchunks ? sumsq8(xraw[i], 0.f) : 0.f;
             }
             __syncthreads();
-            ss = rms_scale_from_partials(part, NUNITS, a.K, part + NUNITS);
+            if (ABL == 3) ts[2] = __builtin_readcyclecounter();
+            ss = rms_scale_from_partials<NUNITS>(part, NUNITS, a.K);
         }
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
 #pragma unroll
         for (int i = 0; i < SLOTS; i++) {
             const unsigned u = tid + i * blockDim.x;
             u32x4 v = xraw[i];
             if (NORM) v = rms_apply8(v, wraw[i], ss);
             if (u >= nchunks) v = (u32x4){0u, 0u, 0u, 0u};
+            const u32x4 pv = permute_x8(v);
+            // x-only correction terms of the 32 inputs of uint4 j (4 consecutive units = one lane quad)
+            float se = __builtin_amdgcn_fdot2(as_h2(pv[0]), ones, 0.f, false);   // x0+x4
+            se = __builtin_amdgcn_fdot2(as_h2(pv[2]), ones, se, false);          // +x2+x6
+            float so = __builtin_amdgcn_fdot2(as_h2(pv[1]), ones, 0.f, false);   // x1+x5
+            so = __builtin_amdgcn_fdot2(as_h2(pv[3]), ones, so, false);          // +x3+x7
+            float ca = __builtin_fmaf(se, 1024.f, so * 64.f);
+            float cb = se + so;
+            ca += dpp_mov<0xB1>(ca); ca += dpp_mov<0x4E>(ca);   // quad sums (the 4 units of one uint4)
+            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
             const unsigned j = u >> 2, d = u & 3u;
-            if (u < NUNITS) xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = permute_x8(v);
+            if (u < NUNITS) {
+                xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+                if (d == 0) sx[j] = make_float2(-ca, -cb);
+            }
         }
         __syncthreads();
     }
+    if (ABL == 3) ts[3] = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = PRE; s < SLOTS; s++) Q4_ISSUE_SLOT(s)
+#undef Q4_ISSUE_SLOT
 
     unsigned M0 = 0x000F000Fu, M1 = 0x00F000F0u, MG = 0x64006400u;
     asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MG));   // keep in VGPRs so (w & M) | MG selects v_and_or_b32
@@ -207,81 +244,127 @@ __global__ void __launch_bounds__(512) gemv_q4_kernel(const GemvArgs a) {
         u32x4 X[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) X[d] = xs[((s * 4 + d) << 6) + lane];
+        const float2 corr = sx[s * 64 + lane];
         const unsigned j = s * 64 + lane;
         const unsigned zsh = ((j >> 2) & 7u) * 4u;
 #pragma unroll
         for (int m = 0; m < NMAT; m++)
 #pragma unroll
             for (int c = 0; c < COLS; c++) {
-                const unsigned z = (ZW[m][s][c] >> zsh) & 0xFu;
-                const float scale = act[s] ? h2f(SC[m][s][c]) : 0.f;
-                const float acc = dot32_q4(W[m][s][c], X, z, M0, M1, MG);
-                colsum[m][c] = __builtin_fmaf(scale, acc, colsum[m][c]);
+                float t;
+                if (ABL == 1) {
+                    const u32x4 w = W[m][s][c];
+                    t = as_f(((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x007FFFFFu) | 0x3F000000u) + as_f(X[s & 3][c & 3] & 0x3FFFFFFFu);
+                } else {
+                    const u32x4 w = W[m][s][c];
+                    float acc_e = corr.x, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d];
+                        const unsigned tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2((ww & M0) | MG), as_h2(X[d][0]), acc_e, false);   // (n0,n4)
+                        acc_o = __builtin_amdgcn_fdot2(as_h2((ww & M1) | MG), as_h2(X[d][1]), acc_o, false);   // (n1,n5) x16
+                        acc_e = __builtin_amdgcn_fdot2(as_h2((tt & M0) | MG), as_h2(X[d][2]), acc_e, false);   // (n2,n6)
+                        acc_o = __builtin_amdgcn_fdot2(as_h2((tt & M1) | MG), as_h2(X[d][3]), acc_o, false);   // (n3,n7) x16
+                    }
+                    const float zf = (float)((ZW[m][s][c] >> zsh) & 0xFu);
+                    t = __builtin_fmaf(acc_o, 0.0625f, acc_e);
+                    t = __builtin_fmaf(zf, corr.y, t);
+                }
+                // idle tail lanes (j >= pw4) multiply re-read weights by the zero padding of xs/sx: exactly 0
+                colsum[m][c] = __builtin_fmaf(h2f(SC[m][s][c]), t, colsum[m][c]);
             }
+        if (ABL == 3 && s < 3) { asm volatile("" : "+v"(colsum[0][0])); ts[4 + s] = __builtin_readcyclecounter(); }
     }
 
-    // ---- 5. wave reduction + epilogue ----------------------------------------------------------
-#pragma unroll
-    for (int m = 0; m < NMAT; m++)
-#pragma unroll
-        for (int c = 0; c < COLS; c++) colsum[m][c] = wave_sum(colsum[m][c]);
+    // ---- 5. transposing wave reduction + lane-parallel epilogue ---------------------------------
+    const int row = lane >> 4;                 // DPP row of this lane = which column's total it will hold
+    const bool writer = (lane & 15u) == 0;
 
-    if (MODE == MODE_PLAIN) {
+    if constexpr (MODE == MODE_PLAIN) {
         q4_half* out = a.out[0];
         if (a.loff != -1) out += (size_t)a.loff + (size_t)(*a.pPos) * a.N;         // gpu_kernels.h:225-227
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < COLS; c++)
-                if (valid[c]) out[col[c]] = f2h(a.accum ? colsum[0][c] + old[c] : colsum[0][c]);   // :229-231
-        }
-    } else if (MODE == MODE_FFN) {
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < COLS; c++) {
-                float val = colsum[0][c];                       // gate
-                val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
-                val *= colsum[1][c];                            // up, :272
-                if (valid[c]) a.out[0][col[c]] = f2h(val);
+        if constexpr (COLS == 4) {
+            const float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+            const int n = wg * 4 + row;
+            if (writer && n < a.N) {
+                float r = tot;
+                if (a.accum) r += h2f(out[n]);                                      // :229-230
+                out[n] = f2h(r);                                                    // :231
+            }
+        } else {   // COLS == 8: row r holds columns 2r (w0) and 2r+1 (w1)
+            const float w0 = reduce4_rows(colsum[0][0], colsum[0][2], colsum[0][4], colsum[0][6]);
+            const float w1 = reduce4_rows(colsum[0][1], colsum[0][3], colsum[0][5], colsum[0][7]);
+            const int n = wg * 8 + row * 2;
+            if (writer && n < a.N) {
+                float r0 = w0, r1 = w1;
+                if (a.accum) { r0 += h2f(out[n]); r1 += h2f(out[n + 1]); }
+                h2 pk = {(f16_t)r0, (f16_t)r1};
+                *reinterpret_cast<unsigned*>(out + n) = as_u(pk);                   // N % 8 == 0: n+1 < N
             }
         }
-    } else {   // MODE_QKV
-        constexpr int P = COLS / 2;
+    } else if constexpr (MODE == MODE_FFN) {
+        float g, u;
+        int n;
+        if constexpr (COLS == 4) {        // row r: gate(col r) in g, up(col r) in u
+            g = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+            u = reduce4_rows(colsum[NMAT - 1][0], colsum[NMAT - 1][1], colsum[NMAT - 1][2], colsum[NMAT - 1][3]);
+            n = wg * 4 + row;
+        } else {                // COLS == 2: rows = gate c0, up c0, gate c1, up c1; fetch the partner row
+            const float w = reduce4_rows(colsum[0][0], colsum[NMAT - 1][0], colsum[0][1], colsum[NMAT - 1][1]);
+            const float o = __shfl_xor(w, 16);
+            g = (row & 1) ? o : w;
+            u = (row & 1) ? w : o;
+            n = wg * 2 + (row >> 1);
+        }
+        float val = g;
+        val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
+        val *= u;                                       // :272
+        const bool wr = COLS == 4 ? writer : (lane & 31u) == 0;
+        if (wr && n < a.N) a.out[0][n] = f2h(val);
+    } else {   // MODE_QKV, COLS == 4: rows = pair0 first, pair1 first, pair0 second, pair1 second
         q4_half* out = a.out[mat0];
         int pos = 0;
         if (mat0 != 0 || a.rope) pos = *a.pPos;
         if (mat0 != 0) out += (size_t)a.loff + (size_t)pos * a.N;                   // gpu_kernels.h:251,253
-        float r[COLS];
-#pragma unroll
-        for (int c = 0; c < COLS; c++) r[c] = colsum[0][c];
+        const float mine = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+        const int hp = a.head_size >> 1;
+        const int p = wg * 2 + (row & 1);                // pair index of this row
+        const int head = p / hp, i = p - head * hp;
+        const int n = head * a.head_size + i + ((row & 2) ? hp : 0);
+        float r = mine;
         if (a.rope && mat0 < 2) {
             // RoPERotation_kernel gpu_kernels.h:332-355 on the fp16-rounded GEMV outputs
-#pragma unroll
-            for (int pi = 0; pi < P; pi++) {
-                const int i = col[pi] % a.head_size;
-                const int head_dim = (i * 2) % a.head_size;
-                const float freq = 1.0f / powf(a.rope_theta, head_dim / (float)a.head_size);
-                const float val = pos * freq;
-                const float fcr = cosf(val), fci = sinf(val);
-                const float v0 = round_h(r[pi]), v1 = round_h(r[P + pi]);
-                r[pi] = v0 * fcr - v1 * fci;
-                r[P + pi] = v0 * fci + v1 * fcr;
+            const float other = round_h(__shfl_xor(mine, 32));
+            const float me = round_h(mine);
+            float fcr, fci;
+            if (a.rope_table != nullptr) {   // same bits as the on-the-fly path: the table was filled by rope_angle()
+                const float2 cs = a.rope_table[(size_t)pos * hp + i];
+                fcr = cs.x; fci = cs.y;
+            } else {
+                rope_angle(i, a.head_size, pos, a.rope_theta, fcr, fci);
             }
+            r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
-        if (lane == 0) {
+        if (writer && n < a.N) out[n] = f2h(r);
+    }
+    if (ABL == 3 && a.dbg != nullptr && lane == 0) {
+        ts[7] = __builtin_readcyclecounter();
+        unsigned long long* d = a.dbg + (size_t)wg * 8;
 #pragma unroll
-            for (int c = 0; c < COLS; c++)
-                if (valid[c]) out[col[c]] = f2h(r[c]);
-        }
+        for (int i = 0; i < 8; i++) d[i] = ts[i];
     }
 }
 
 // host-side dispatch -------------------------------------------------------------------------------
-template <int MODE, int SLOTS, int COLS, bool NORM>
+extern int g_ablate;
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0>
 static int launch_one(const GemvArgs& a, int waves) {
+    if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS / 64;
     const int cols_per_block = COLS * waves;
     dim3 grid(divUp(a.N, cols_per_block), MODE == MODE_QKV ? 3 : 1);
-    const size_t smem = (size_t)SLOTS * 256 * 16 + (size_t)SLOTS * 256 * 4 + 16;
-    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM>), grid, dim3(waves * 64), smem, a);
+    const size_t smem = (size_t)SLOTS * 256 * 16 + (size_t)SLOTS * 512 + (size_t)SLOTS * 256 * 4 + 16;
+    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL>), grid, dim3(waves * 64), smem, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }

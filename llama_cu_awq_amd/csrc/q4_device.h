@@ -76,25 +76,38 @@ __device__ __forceinline__ float sumsq8(u32x4 v, float acc) {
     return acc;
 }
 
-// Canonical rmsnorm reduction (block-size independent, so the standalone rmsnorm kernel and every
-// fused consumer produce the same bits): per-16B-chunk partials in LDS, then ONE wave sums them
-// lane-strided by 64 and tree-reduces. `part` holds `nchunks` floats. Returns 1/sqrt(mean+eps) to all.
+// Canonical rmsnorm reduction (block-size independent, so the standalone rmsnorm kernel and every fused
+// consumer produce the same bits): per-16B-chunk partials in LDS, then EVERY wave sums them lane-strided by 64
+// and tree-reduces on its own -- redundant, but it needs no second barrier and no serial LDS chain on one wave.
+// `part` holds `nchunks` floats (NCH > 0: compile-time count). Returns 1/sqrt(mean + eps).
 // Caller: every thread has written part[] for its chunks and called __syncthreads() before.
-__device__ __forceinline__ float rms_scale_from_partials(const float* part, int nchunks, int size, float* bcast) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        float s = 0.f;
-        for (int u = tid; u < nchunks; u += 64) s += part[u];
-        s = wave_sum(s);
-        if (tid == 0) {
-            float ss = s / (float)size;        // gpu_kernels.h:88
-            ss += 1e-5f;                       // :89
-            ss = 1.0f / sqrtf(ss);             // :90
-            *bcast = ss;
-        }
+template <int NCH>
+__device__ __forceinline__ float rms_scale_from_partials(const float* part, int nchunks, int size) {
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    if constexpr (NCH > 0) {
+        constexpr int R = (NCH + 63) / 64;
+        float v[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) v[i] = (lane + 64 * i < NCH) ? part[lane + 64 * i] : 0.f;   // independent LDS reads
+#pragma unroll
+        for (int i = 0; i < R; i++) s += v[i];
+    } else {
+        for (int u = lane; u < nchunks; u += 64) s += part[u];
     }
-    __syncthreads();
-    return *bcast;
+    s = wave_sum(s);
+    float ss = s / (float)size;        // gpu_kernels.h:88
+    ss += 1e-5f;                       // :89
+    return 1.0f / sqrtf(ss);           // :90
+}
+
+// RoPE angle of pair index i at position pos: RoPERotation_kernel gpu_kernels.h:338-342
+__device__ __forceinline__ void rope_angle(int i, int head_size, int pos, float rope_theta, float& fcr, float& fci) {
+    const int head_dim = (i * 2) % head_size;
+    const float freq = 1.0f / powf(rope_theta, head_dim / (float)head_size);
+    const float val = pos * freq;
+    fcr = cosf(val);
+    fci = sinf(val);
 }
 
 // normalise 8 halves: half(x * (ss * w))   gpu_kernels.h:100-102

@@ -13,7 +13,9 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 
 // launch shapes (columns per wave, waves per block); tuned on MI355X, see DESIGN.md
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
-static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {2, 4}, {4, 4}, {2, 4}};
+int g_ablate = 0;
+unsigned long long* g_dbg = nullptr;
+static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {4, 4}, {4, 4}, {4, 4}};
 
 // ------------------------------------------------------------------------------------------------
 // rmsnorm_kernel (gpu_kernels.h:72-105). One block; 16-byte loads; the canonical chunk-partial reduction
@@ -25,7 +27,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(q4_half* o, const q4_half*
     for (int u = threadIdx.x; u < nchunks; u += blockDim.x)
         part[u] = sumsq8(reinterpret_cast<const u32x4*>(x)[u], 0.f);
     __syncthreads();
-    const float ss = rms_scale_from_partials(part, nchunks, size, part + nchunks);
+    const float ss = rms_scale_from_partials<0>(part, nchunks, size);
     for (int u = threadIdx.x; u < nchunks; u += blockDim.x)
         reinterpret_cast<u32x4*>(o)[u] =
             rms_apply8(reinterpret_cast<const u32x4*>(x)[u], reinterpret_cast<const u32x4*>(weight)[u], ss);
@@ -91,10 +93,8 @@ __global__ void rope_kernel(q4_half* sq, q4_half* sk_base, int num_kv_heads, int
     const int h = blockIdx.x;
     q4_half* q = sq + (size_t)h * head_size;
     const int i = threadIdx.x;
-    const int head_dim = (i * 2) % head_size;
-    const float freq = 1.0f / powf(rope_theta, head_dim / (float)head_size);
-    const float val = pos * freq;
-    const float fcr = cosf(val), fci = sinf(val);
+    float fcr, fci;
+    rope_angle(i, head_size, pos, rope_theta, fcr, fci);
     const float q0 = h2f(q[i]), q1 = h2f(q[i + head_size / 2]);
     q[i] = f2h(q0 * fcr - q1 * fci);
     q[i + head_size / 2] = f2h(q0 * fci + q1 * fcr);
@@ -122,86 +122,107 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-    // red: 16 floats + 1. all threads participate.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    v = is_max ? wave_max(v) : wave_sum(v);
-    __syncthreads();                       // previous users of red[] are done
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float r = red[0];
-    for (int w = 1; w < nw; w++) r = is_max ? fmaxf(r, red[w]) : r + red[w];
-    return r;
-}
+constexpr int ATT_NW = 16;   // waves per attention block (one block per head)
 
 template <int LPR>
-__global__ void __launch_bounds__(1024) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
-                                                         const q4_half* value_cache, int head_size, int kv_mul,
-                                                         int kv_dim, const int* pPos, float alpha, int lds_scores) {
+__global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
+                                                                const q4_half* value_cache, int head_size, int kv_mul,
+                                                                int kv_dim, const int* pPos, float alpha, int lds_scores) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr int U = 4;                   // wave instructions in flight per pass
+    constexpr int NW = ATT_NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem);             // 32 floats
-    float* sc = red + 32;                                    // [lds_scores] scores / exps
+    float* red_max = reinterpret_cast<float*>(smem);         // [16]
+    float* red_sum = red_max + 16;                           // [16]
+    float* outp = red_sum + 16;                              // [NW][head_size] output partials
+    float* sc = outp + NW * head_size;                       // [lds_scores] scores, then exps
     const int h = blockIdx.x;
-    const int size = *pPos + 1;
     const unsigned tid = threadIdx.x, lane = tid & 63u;
-    const int wave = tid >> 6, nw = blockDim.x >> 6;
+    const int wave = tid >> 6;
     const int row = lane / LPR, sub = lane % LPR;            // position within the instruction, 16-B slice of the row
-    const int stride = nw * R;                               // positions per block step
+    constexpr int stride = NW * R;                           // positions per block step
+    constexpr int group = stride * U;                        // positions per block pass (256 for head 128)
     const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
     const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    const int size = *pPos + 1;
+
+    // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
+    // context <= `group` positions (rows are clamped to pos, so only cache-warm rows are touched)
+    u32x4 kv0[U], vv0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = wave * R + row + u * stride;
+        const int tc = t < size ? t : size - 1;
+        kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+        vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+    }
     const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
 
     // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
-    for (int tb = wave * R; tb < size; tb += stride * U) {
+    float wmax = -INFINITY;
+    for (int g0 = 0; g0 < size; g0 += group) {
         u32x4 kv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int t = tb + row + u * stride;
-            const int tc = t < size ? t : size - 1;
-            kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+            if (g0 == 0) {
+                kv[u] = kv0[u];
+            } else {
+                const int t = g0 + wave * R + row + u * stride;
+                const int tc = t < size ? t : size - 1;
+                kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int t = tb + row + u * stride;
+            const int t = g0 + wave * R + row + u * stride;
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
             s = row_sum<LPR>(s);
-            s *= alpha;
-            if (sub == 0 && t < size) sc[t] = round_h(s);                         // gpu_kernels.h:167
+            s = round_h(s * alpha);                                               // gpu_kernels.h:164-167
+            if (t < size) {
+                wmax = fmaxf(wmax, s);
+                if (sub == 0) sc[t] = s;
+            }
         }
     }
-    __syncthreads();
+    wmax = wave_max(wmax);
+    if (lane == 0) red_max[wave] = wmax;
+    __syncthreads();                                                              // barrier 1: scores + wave maxima
 
     // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
-    float m = -INFINITY;
-    for (int t = tid; t < size; t += blockDim.x) m = fmaxf(m, sc[t]);
-    m = block_reduce(m, red, true);
+    const float m = row16_max(red_max[lane & 15]);
     float sum = 0.f;
-    for (int t = tid; t < size; t += blockDim.x) {
+    for (int t = tid; t < size; t += NW * 64) {
         const float e = expf(sc[t] - m);
         sc[t] = e;
         sum += e;
     }
-    sum = block_reduce(sum, red, false);      // barriers inside also publish sc[]
+    sum = wave_sum(sum);
+    if (lane == 0) red_sum[wave] = sum;
+    __syncthreads();                                                              // barrier 2: exps + wave sums
+    // fixed order: DPP tree over the 16 wave sums
+    sum = row16_sum(red_sum[lane & 15]);
 
     // ---- pass 2: att . V -----------------------------------------------------------------------------
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (int tb = wave * R; tb < size; tb += stride * U) {
+    for (int g0 = 0; g0 < size; g0 += group) {
         u32x4 vv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int t = tb + row + u * stride;
-            const int tc = t < size ? t : size - 1;
-            vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+            if (g0 == 0) {
+                vv[u] = vv0[u];
+            } else {
+                const int t = g0 + wave * R + row + u * stride;
+                const int tc = t < size ? t : size - 1;
+                vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int t = tb + row + u * stride;
+            const int t = g0 + wave * R + row + u * stride;
             const float p = t < size ? round_h(sc[t] / sum) : 0.f;                // gpu_kernels.h:400
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -211,7 +232,7 @@ __global__ void __launch_bounds__(1024) attention_kernel(q4_half* output, const 
             }
         }
     }
-    // combine the R rows of a wave (DPP/shuffle across row groups), then the waves through LDS
+    // combine the R rows of a wave (shuffle across row groups), then the waves through LDS
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v = acc[e];
@@ -221,16 +242,18 @@ __global__ void __launch_bounds__(1024) attention_kernel(q4_half* output, const 
         if (LPR <= 4) v += __shfl_xor(v, 4);
         acc[e] = v;
     }
-    __syncthreads();                          // everyone is done reading sc[]
-    float* outp = sc;                         // reuse: [nw][head_size]
     if (lane < LPR) {
 #pragma unroll
         for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
     }
-    __syncthreads();
-    for (int n = tid; n < head_size; n += blockDim.x) {
+    __syncthreads();                                                              // barrier 3: output partials
+    for (int n = tid; n < head_size; n += NW * 64) {
+        float part[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];           // independent LDS reads
         float s = 0.f;
-        for (int w = 0; w < nw; w++) s += outp[w * head_size + n];
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += part[w];
         output[(size_t)h * head_size + n] = f2h(s);
     }
 }
@@ -289,6 +312,43 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
     }
 }
 
+// (cos, sin) of every (position, pair) with the reference's own formula, so that table lookups in the fused QKV
+// epilogue are bit-identical to RoPERotation_kernel's on-the-fly powf/cosf/sinf (~300 VALU per wave saved)
+__global__ void rope_table_kernel(float2* table, int seq_len, int head_size, float rope_theta) {
+    const int hp = head_size >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= seq_len * hp) return;
+    float c, s;
+    rope_angle(idx % hp, head_size, idx / hp, rope_theta, c, s);
+    table[idx] = make_float2(c, s);
+}
+
+struct RopeTable { float2* ptr; int seq_len; int head_size; float theta; };
+static RopeTable g_rope_tables[4] = {};
+
+const float2* rope_table_lookup(int head_size, float theta) {
+    for (auto& t : g_rope_tables)
+        if (t.ptr && t.head_size == head_size && t.theta == theta) return t.ptr;
+    return nullptr;
+}
+int rope_table_build(int seq_len, int head_size, float theta) {
+    for (auto& t : g_rope_tables)
+        if (t.ptr && t.head_size == head_size && t.theta == theta && t.seq_len >= seq_len) return Q4_OK;
+    for (auto& t : g_rope_tables)
+        if (!t.ptr || (t.head_size == head_size && t.theta == theta)) {
+            if (t.ptr) hipFree(t.ptr);
+            t.ptr = nullptr;
+            Q4_HIP(hipMalloc((void**)&t.ptr, (size_t)seq_len * (head_size / 2) * sizeof(float2)));
+            t.seq_len = seq_len; t.head_size = head_size; t.theta = theta;
+            const int n = seq_len * (head_size / 2);
+            Q4_LAUNCH(rope_table_kernel, dim3(divUp(n, 256)), dim3(256), 0, t.ptr, seq_len, head_size, theta);
+            Q4_LAUNCH_CHECK();
+            Q4_HIP(hipStreamSynchronize(g_stream));
+            return Q4_OK;
+        }
+    return Q4_OK;   // no free slot: the kernels fall back to computing the angles
+}
+
 // ---- fused-path launchers used by the network -----------------------------------------------------
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
 
@@ -312,6 +372,7 @@ int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, con
     a.out[0] = q; a.out[1] = kc; a.out[2] = vc;
     a.x = x; a.rms_w = rms_w; a.pPos = pPos; a.loff = loff;
     a.rope = head_size > 0; a.head_size = head_size > 0 ? head_size : 2; a.rope_theta = rope_theta;
+    a.rope_table = head_size > 0 ? rope_table_lookup(head_size, rope_theta) : nullptr;
     return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
 }
 
@@ -321,7 +382,7 @@ int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const
     int rc = fill_geom(a, dim, hidden);
     if (rc) return rc;
     fill_mat(a.m[0], gate); fill_mat(a.m[1], up);
-    a.out[0] = out; a.x = x; a.rms_w = rms_w;
+    a.out[0] = out; a.x = x; a.rms_w = rms_w; a.dbg = g_dbg;
     return launch_gemv_ffn(a, g_tune[TUNE_FFN].cols, g_tune[TUNE_FFN].waves);
 }
 
@@ -333,6 +394,9 @@ using namespace q4;
 // C ABI
 // =================================================================================================
 extern "C" {
+
+void q4_set_ablate(int mode) { g_ablate = mode; }
+void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 
 void q4_set_gemv_tune(int kind, int cols, int waves) {
     if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }
@@ -401,25 +465,26 @@ int q4_rope_rotation(q4_half* q, q4_half* k, int num_heads, int num_kv_heads, in
     return Q4_OK;
 }
 
-int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                            q4_half* att, int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos) {
-    (void)att;
+}  // extern "C"
+
+namespace q4 {
+int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
+                     int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, int kv_rows) {
+    (void)kv_rows;
     const int dim = head_size * num_heads;
     const int kv_dim = dim / kv_mul;
     const float alpha = (float)(1.0 / sqrt((double)head_size));                     // llama2_q4.cu:273
-    constexpr int NW = 16;
-    // LDS: 32 reduction floats + max(seq scores, NW*head_size output partials) floats
-    int lds_floats = max_seq_len > NW * head_size ? max_seq_len : NW * head_size;
-    const size_t smem = (size_t)(32 + lds_floats) * 4;
-    if (smem > 160 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;                          // > ~40K positions
-    dim3 grid(num_heads), block(NW * 64);
+    // LDS: 32 reduction floats + NW*head_size output partials + one fp32 score per position
+    const size_t smem = (size_t)(32 + ATT_NW * head_size + max_seq_len) * 4;
+    if (smem > 160 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;                          // > ~38K positions
+    dim3 grid(num_heads), block(ATT_NW * 64);
 #define Q4_ATT(L)                                                                                                  \
     {                                                                                                              \
         if (smem > 64 * 1024)                                                                                      \
             Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                \
-        Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache,   \
-                           head_size, kv_mul, kv_dim, pPos, alpha, lds_floats);                                    \
+        Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache, head_size, kv_mul,  \
+                  kv_dim, pPos, alpha, max_seq_len);                                                               \
     }
     switch (head_size) {
         case 32: Q4_ATT(4) break;
@@ -431,6 +496,15 @@ int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* ke
 #undef Q4_ATT
     Q4_LAUNCH_CHECK();
     return Q4_OK;
+}
+}  // namespace q4
+
+extern "C" {
+
+int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
+                            q4_half* att, int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos) {
+    (void)att;
+    return launch_attention(output, q, key_cache, value_cache, num_heads, head_size, kv_mul, max_seq_len, pPos, 0);
 }
 
 int q4_copy_embedding(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {

@@ -300,6 +300,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         return rc;
     }
     g_slabs[t] = slabs;
+    if (p->dim == kv_dim) rope_table_build(p->seq_len, p->dim / p->n_heads, p->rope_theta);   // fused QKV+RoPE path only
     return Q4_OK;
 }
 
@@ -368,8 +369,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache, p->n_heads, p->n_kv_heads, head_size, pPos, loff, p->rope_theta));   // :317
         }
-        Q4_TRY(q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads,
-                                       head_size, kv_mul, seq_len_bin, pPos));                          // :320
+        Q4_TRY(launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
+                                seq_len_bin, pPos, g_fusion ? p->seq_len : 0));                         // :320
         Q4_TRY(q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                         // :323
         if (g_fusion) {
             Q4_TRY(launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329

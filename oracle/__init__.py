@@ -31,10 +31,33 @@ def build(force=False):
     return so
 
 
+def effective_cpus():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (a container that sees
+    256 cores but owns 16 would otherwise oversubscribe OpenMP 16x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(min(effective_cpus(), 64))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     L = C.CDLL(build())
     L.orc_init.restype = None
     L.orc_h2f.restype = C.c_float
