@@ -71,7 +71,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_dist
 
-    from llama_cu_awq_amd import api, synth   # raises if libllama2_q4.so is missing: no fallback
+    from llama_cu_awq_amd import api, synth, replicas   # raises if libllama2_q4.so is missing: no fallback
     L = api.lib()
     api.check(L.q4_set_device(local_rank if world > 1 else 0))
     if args.no_graphs:
@@ -84,8 +84,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
-        sync_t = torch.zeros(1, device="cuda")
+        dist = replicas.init("nccl", rank, world)   # nccl == RCCL on ROCm; barrier + two scalar reductions only
 
     def barrier():
         api.check(L.q4_device_synchronize())
@@ -133,15 +132,7 @@ def main():
             tokens0 = toks
     barrier()
     elapsed = time.perf_counter() - t0
-    total_tokens = timed_tokens
-    if use_dist:
-        import torch
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tk = torch.tensor([timed_tokens], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        total_tokens = int(tk.item())
+    elapsed, total_tokens = replicas.aggregate(elapsed, timed_tokens, dist if use_dist else None, device="cuda")
     value = total_tokens / elapsed
 
     # ---- per-kernel durations (dispatch timestamps, ring over the layers' weights) ------------------

@@ -32,6 +32,7 @@ GEOMETRIES = {
     "tiny": (256, 352, 2, 4, 4, 512, 64, 10000.0),
     "tiny_gqa": (256, 352, 2, 8, 2, 512, 64, 10000.0),
     "small": (512, 1408, 3, 8, 8, 1024, 320, 10000.0),
+    "micro": (64, 96, 2, 2, 2, 128, 32, 10000.0),       # committed fixture tests/golden/micro_model.bin (~60 KB)
 }
 
 

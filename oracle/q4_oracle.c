@@ -408,6 +408,12 @@ unsigned int orc_random_u32(unsigned long long *state) {
 }
 float orc_random_f32(unsigned long long *state) { return (orc_random_u32(state) >> 8) / 16777216.0f; }
 
+/* balanced pairwise tree over n = 2^k values in natural order */
+static float pairwise_sum(const float *v, int n) {
+    if (n == 1) return v[0];
+    return pairwise_sum(v, n / 2) + pairwise_sum(v + n / 2, n / 2);
+}
+
 /* ---- temperature / top-p sampling: sampler.h:51-81, gpu_kernels.h:499-584 ----------
  * softmax_logits_kernel (fp16 rounding at: logits/temperature, exp, normalise),
  * descending sort of fp16 probabilities (cub radix sort is stable: equal keys keep
@@ -431,7 +437,8 @@ int orc_sample_topp(f16 *logits, int n, float temperature, float topp, float coi
         for (int i = tid; i < n; i += 1024) { float v = expf(h2f(logits[i]) - max_val); logits[i] = f2h(v); sum += v; }
         part[tid] = sum;
     }
-    float sum = block_sum1024(part);
+    /* cub's BlockReduce order is unspecified; restated as the balanced pairwise tree the HIP kernel uses */
+    float sum = pairwise_sum(part, 1024);
     for (int t = 0; t < n; t++) logits[t] = f2h(h2f(logits[t]) / sum);
     uint32_t *kv = (uint32_t *)malloc(sizeof(uint32_t) * 2 * n);
     for (int t = 0; t < n; t++) { kv[2 * t] = logits[t]; kv[2 * t + 1] = (uint32_t)t; }

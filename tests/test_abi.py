@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a CPU-only host and exports every function include/llama2_q4.h declares."""
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "llama2_q4.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    body = src[src.index('extern "C" {'):]
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", body):
+        n = m.group(1)
+        if n.startswith(("q4_", "build_sampler", "destroy_sampler", "random_", "compute_perplexity")) and not n.endswith("_t"):
+            names.add(n)
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from llama_cu_awq_amd import api
+    declared = _declared_functions()
+    assert len(declared) > 50
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = sorted(declared - exported)
+    assert not missing, "declared in llama2_q4.h but not exported: %s" % missing
+    assert set(api.SYMBOLS) <= exported
+
+
+def test_library_loads_without_gpu_and_reports_status_strings():
+    from llama_cu_awq_amd import api
+    L = api.lib()
+    assert L.q4_status_string(0) == b"ok"
+    assert L.q4_status_string(1) == b"Unsupported matmul size. Exiting"      # llama2_q4.cu:215
+    assert L.q4_get_fusion() in (0, 1)
+
+
+def test_struct_layouts_match_the_reference():
+    """Config is fread raw from the file (llama2_q4.cu:414): 8 x 4 bytes; QWeight = 3 pointers (common.h:20-24)."""
+    import ctypes as C
+    from llama_cu_awq_amd import api
+    assert C.sizeof(api.Config) == 32
+    assert [f[0] for f in api.Config._fields_] == ["dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size", "seq_len", "rope_theta"]
+    assert C.sizeof(api.QWeight) == 24 and C.sizeof(api.PerLayerWeight) == 16 + 7 * 24
+    assert [f[0] for f in api.RunState._fields_] == ["x", "xb", "hb", "q", "att", "logits", "key_cache", "value_cache", "pos", "shared_data", "logits_array"]
+
+
+def test_no_product_code_touches_the_oracle():
+    """The product (llama_cu_awq_amd/) must never import, link or execute anything under oracle/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "llama_cu_awq_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                if re.search(r"\boracle\b", txt) and "import oracle" in txt or "liboracle" in txt or "q4_oracle" in txt:
+                    bad.append(os.path.join(dirpath, fn))
+    assert not bad, bad

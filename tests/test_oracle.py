@@ -1,0 +1,101 @@
+"""The CPU restatement against analytic checks and the committed fixtures (regression pins)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from llama_cu_awq_amd import synth
+
+
+def test_f16_conversions_exact(orc):
+    L = orc.lib()
+    allh = np.arange(65536, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    for h in range(0, 65536, 7):
+        v = L.orc_h2f(h)
+        assert (np.isnan(v) and np.isnan(f[h])) or v == f[h]
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.standard_normal(3000).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1, 100, 30000)])
+    for v in vals:
+        assert L.orc_f2h(float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16))
+    for h in range(0, 0x7bff, 97):     # exact midpoints round to even
+        mid = np.float32((float(np.uint16(h).view(np.float16)) + float(np.uint16(h + 1).view(np.float16))) / 2)
+        assert L.orc_f2h(float(mid)) == int(mid.astype(np.float16).view(np.uint16))
+
+
+@pytest.mark.parametrize("K,N", [(352, 64), (4096, 32), (256, 8), (11008, 16)])
+def test_gemv_lane_order_vs_fp64_dense(orc, rng, K, N):
+    w, z, s = synth.random_qweight(rng, K, N)
+    x = rng.standard_normal(K).astype(np.float16)
+    o16 = orc.matmul_q4(x, w, z, s, K, N)
+    o64 = orc.matmul_q4_f64(x, w, z, s, K, N)
+    dense = synth.dequant_dense(w, z, s, K, N) @ x.astype(np.float64)
+    assert np.abs(o64 - dense).max() < 1e-9
+    assert np.abs(o16.astype(np.float64) - o64).max() <= 2.0 ** -10 * np.abs(o64).max() + 1e-6
+
+
+def test_accum_and_kv_addressing(orc, rng):
+    K, N = 256, 64
+    w, z, s = synth.random_qweight(rng, K, N)
+    x = rng.standard_normal(K).astype(np.float16)
+    base = orc.matmul_q4_f64(x, w, z, s, K, N)
+    old = rng.standard_normal(N).astype(np.float16)
+    acc = orc.matmul_q4(x, w, z, s, K, N, accum_into=old)
+    assert np.abs(acc.astype(np.float64) - (base + old.astype(np.float64))).max() < 4e-3
+    buf = np.zeros(5 * N, dtype=np.float16)
+    orc.matmul_q4(x, w, z, s, K, N, loff=N, pos=2, out=buf)
+    assert (buf[:3 * N] == 0).all() and (buf[4 * N:] == 0).all() and (buf[3 * N:4 * N] != 0).any()
+
+
+def test_rmsnorm_rope_attention_against_numpy(orc, rng):
+    x = rng.standard_normal(512).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(512)).astype(np.float16)
+    xf = x.astype(np.float64)
+    ref = xf / np.sqrt((xf ** 2).mean() + 1e-5) * w.astype(np.float64)
+    assert np.abs(orc.rmsnorm(x, w).astype(np.float64) - ref).max() < 4e-3
+    # rope: rotation preserves pair norms
+    q = rng.standard_normal(4 * 64).astype(np.float16)
+    k = rng.standard_normal(4 * 64).astype(np.float16)
+    rq, rk = orc.rope(q, k, 4, 4, 64, 17, 10000.0)
+    a, b = q.reshape(4, 2, 32).astype(np.float64), rq.reshape(4, 2, 32).astype(np.float64)
+    assert np.allclose((a ** 2).sum(axis=1), (b ** 2).sum(axis=1), rtol=5e-3, atol=1e-3)
+    q0, _ = orc.rope(q, k, 4, 4, 64, 0, 10000.0)
+    assert np.array_equal(q0, q)                     # position 0 is the identity
+    # attention vs fp64 softmax(QK^T/sqrt(d)) V
+    heads, hs, pos = 4, 64, 9
+    kc = rng.standard_normal((pos + 1) * heads * hs).astype(np.float16)
+    vc = rng.standard_normal((pos + 1) * heads * hs).astype(np.float16)
+    out, att = orc.attention(q, kc, vc, heads, hs, 1, pos)
+    Q = q.reshape(heads, hs).astype(np.float64)
+    K = kc.reshape(pos + 1, heads, hs).astype(np.float64)
+    V = vc.reshape(pos + 1, heads, hs).astype(np.float64)
+    sc = np.einsum("hd,thd->ht", Q, K) / np.sqrt(hs)
+    p = np.exp(sc - sc.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    ref = np.einsum("ht,thd->hd", p, V).reshape(-1)
+    assert np.abs(out.astype(np.float64) - ref).max() < 1e-2
+    assert np.abs(att.astype(np.float64) - p).max() < 2e-3
+
+
+def test_micro_model_fixture_regression(orc):
+    """Committed fixture: the oracle must keep reproducing its own recorded logits / tokens / KV bit for bit."""
+    exp = np.load(os.path.join(GOLDEN, "micro_model_expected.npz"))
+    m = orc.Model(os.path.join(GOLDEN, "micro_model.bin"))
+    toks, logits = m.generate_greedy(exp["prompt"], 20, want_logits=True)
+    assert np.array_equal(toks, exp["tokens"])
+    assert np.array_equal(logits.astype(np.float16).view(np.uint16), exp["logits"].view(np.uint16))
+    k, v = m.kv()
+    assert np.array_equal(k[:, :20].view(np.uint16), exp["k"].view(np.uint16))
+    assert np.array_equal(v[:, :20].view(np.uint16), exp["v"].view(np.uint16))
+    m.close()
+
+
+def test_sampler_restatement_basic(orc, rng):
+    """top-p restatement: with topp=1 the threshold is the coin itself; a peaked distribution returns its mode."""
+    n = 512
+    logits = rng.standard_normal(n).astype(np.float16)
+    logits[77] = np.float16(30.0)
+    L = orc.lib()
+    assert L.orc_sample_topp(orc.f16_bits(logits.copy()), n, 1.0, 0.9, 0.5) == 77
+    assert L.orc_sample_topp(orc.f16_bits(logits.copy()), n, 1.0, 1.0, 0.5) == 77
