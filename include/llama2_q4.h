@@ -301,6 +301,11 @@ int q4_parse_args(int argc, char** argv, q4_cli_args* out);
  *   5: fp16 classifier (ring ignored)  */
 double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
                        double* min_us, double* max_us);
+/* Steady-state cost of one launch of kernel_id INSIDE a hipGraph (kernel + boundary, what the decode loop pays):
+ * `iters` launches over the ring of layers are captured into one graph and replayed `reps` times; wall-clock
+ * microseconds per launch. ids as above, plus 6: attention, 7: rmsnorm, 8: argmax, 9: embedding copy. */
+double q4_bench_kernel_graph(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
+                             int reps);
 int q4_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes);
 
 #ifdef __cplusplus

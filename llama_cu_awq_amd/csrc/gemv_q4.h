@@ -96,22 +96,31 @@ __device__ __forceinline__ float reduce4_rows(float v0, float v1, float v2, floa
 template <int MODE, int SLOTS, int COLS>
 struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
 
-template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0>
+// KS = 2 (PLAIN only): two waves share a column group, each takes SLOTS of the KS*SLOTS k-slots and the partial
+// totals meet in LDS. The N = dim projections (o, down) have only N/4 = 1024 column groups = one wave per SIMD, and a
+// single wave issues one VALU instruction per ~5.5 cycles (measured) -- the ~1000-instruction down-projection wave
+// was a 3.4 us serial chain; splitting K doubles the waves and halves that chain.
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1>
 __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
     static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
-    constexpr int NUNITS = SLOTS * 256;         // 16-byte LDS units (zero padded past K)
+    static_assert(KS == 1 || (KS == 2 && MODE == MODE_PLAIN && COLS == 4), "K split: plain GEMV, 4 columns");
+    constexpr int TS = SLOTS * KS;              // k-slots of the whole column (this wave handles SLOTS of them)
+    constexpr int NUNITS = TS * 256;            // 16-byte LDS units (zero padded past K)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem);                                   // [SLOTS][4][64] permuted x
     float2* sx = reinterpret_cast<float2*>(smem + (size_t)NUNITS * 16);           // [SLOTS][64] (-(1024Se+64So), -(Se+So))
-    float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16 + SLOTS * 512);   // [NUNITS] chunk partials
+    float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16 + TS * 512);   // [NUNITS] chunk partials / K-split exchange
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: column offsets stay in SGPRs
     const int nw = blockDim.x >> 6;
-    const int wg = blockIdx.x * nw + wave;      // global wave index
+    const int wg = blockIdx.x * (nw / KS) + wave / KS;   // global column-group index
+    const int khalf = wave % KS;
+    const int sbase = khalf * SLOTS;            // first k-slot of this wave
+    const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
     const int mat0 = (MODE == MODE_QKV) ? blockIdx.y : 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ABL == 3) ts[0] = __builtin_readcyclecounter();
@@ -138,10 +147,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     for (int c = 0; c < COLS; c++) colc[c] = col[c] < a.N ? col[c] : a.N - 1;
 
     // ---- 1. activation loads first: their wait (counted vmcnt) leaves the weight loads in flight ----
-    const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
-    u32x4 xraw[SLOTS], wraw[SLOTS];
+    u32x4 xraw[TS], wraw[TS];
 #pragma unroll
-    for (int i = 0; i < SLOTS; i++) {
+    for (int i = 0; i < TS; i++) {
         const unsigned u = tid + i * blockDim.x;
         const unsigned uc = u < nchunks ? u : nchunks - 1;  // clamped, branch-free
         xraw[i] = reinterpret_cast<const u32x4*>(a.x)[uc];
@@ -155,7 +163,10 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     // Buffer loads: descriptor per tensor (SGPRs), wave-uniform column byte offset in soffset (SGPR), the lane's
     // offset inside the column in voffset (one VGPR per slot, shared by every column and matrix) -> no per-load
     // address arithmetic on the VALU. aux = 2 is the non-temporal hint (weights are read once per token).
-    constexpr int PRE = (SLOTS + 1) / 2;
+    // measured on MI355X (tools/sweep_gemv.py): for K <= 8192 staging FIRST wins (QKV 8.1 -> 7.4 us, gate 6.3 -> 5.7 us):
+    // the x chain is short when no weight request is queued ahead of it; for the long-K down projection
+    // (6-7 slots, 1 wave per SIMD) half of the loads in front of the staging hides it better (7.5 -> 7.2 us)
+    constexpr int PRE = SLOTS >= 6 ? (SLOTS + 1) / 2 : 0;
     u32x4 W[NMAT][SLOTS][COLS];
     unsigned ZW[NMAT][SLOTS][COLS];
     uint16_t SC[NMAT][SLOTS][COLS];
@@ -169,7 +180,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     }
 #define Q4_ISSUE_SLOT(s)                                                                                          \
     {                                                                                                             \
-        const unsigned j = (s) * 64 + lane;                                                                       \
+        const unsigned j = (sbase + (s)) * 64 + lane;                                                             \
         const unsigned jj = j < (unsigned)a.pw4 ? j : (unsigned)a.pw4 - 1; /* tail lanes re-read the last unit */ \
         _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c++) {       \
             ZW[m][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4, colc[c] * a.pzh * 4, 0);     \
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         float ss = 1.f;
         if (NORM) {
 #pragma unroll
-            for (int i = 0; i < SLOTS; i++) {
+            for (int i = 0; i < TS; i++) {
                 const unsigned u = tid + i * blockDim.x;
                 if (u < NUNITS) part[u] = u < nchunks ? sumsq8(xraw[i], 0.f) : 0.f;
             }
@@ -200,7 +211,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         }
         const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
 #pragma unroll
-        for (int i = 0; i < SLOTS; i++) {
+        for (int i = 0; i < TS; i++) {
             const unsigned u = tid + i * blockDim.x;
             u32x4 v = xraw[i];
             if (NORM) v = rms_apply8(v, wraw[i], ss);
@@ -243,9 +254,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     for (int s = 0; s < SLOTS; s++) {
         u32x4 X[4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[d] = xs[((s * 4 + d) << 6) + lane];
-        const float2 corr = sx[s * 64 + lane];
-        const unsigned j = s * 64 + lane;
+        for (int d = 0; d < 4; d++) X[d] = xs[(((sbase + s) * 4 + d) << 6) + lane];
+        const float2 corr = sx[(sbase + s) * 64 + lane];
+        const unsigned j = (sbase + s) * 64 + lane;
         const unsigned zsh = ((j >> 2) & 7u) * 4u;
 #pragma unroll
         for (int m = 0; m < NMAT; m++)
@@ -285,9 +296,14 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         q4_half* out = a.out[0];
         if (a.loff != -1) out += (size_t)a.loff + (size_t)(*a.pPos) * a.N;         // gpu_kernels.h:225-227
         if constexpr (COLS == 4) {
-            const float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+            float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
             const int n = wg * 4 + row;
-            if (writer && n < a.N) {
+            if (KS == 2) {                      // fixed order: lower k half + upper k half
+                if (writer) part[wave * 4 + row] = tot;
+                __syncthreads();
+                if (khalf == 0) tot += part[(wave + 1) * 4 + row];
+            }
+            if (writer && khalf == 0 && n < a.N) {
                 float r = tot;
                 if (a.accum) r += h2f(out[n]);                                      // :229-230
                 out[n] = f2h(r);                                                    // :231
@@ -358,13 +374,15 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
 // host-side dispatch -------------------------------------------------------------------------------
 extern int g_ablate;
-template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0>
+extern int g_ksplit;    // 1: split K over two waves for the plain GEMV (default), 0: one wave per column group
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1>
 static int launch_one(const GemvArgs& a, int waves) {
     if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS / 64;
-    const int cols_per_block = COLS * waves;
+    const int cols_per_block = COLS * (waves / KS);
     dim3 grid(divUp(a.N, cols_per_block), MODE == MODE_QKV ? 3 : 1);
-    const size_t smem = (size_t)SLOTS * 256 * 16 + (size_t)SLOTS * 512 + (size_t)SLOTS * 256 * 4 + 16;
-    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL>), grid, dim3(waves * 64), smem, a);
+    constexpr int TS = SLOTS * KS;
+    const size_t smem = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
+    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>), grid, dim3(waves * 64), smem, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }

@@ -1,8 +1,60 @@
 // q4_bench.hip -- per-kernel timing with dispatch timestamps over a ring of distinct weight sets (bench.py).
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <vector>
 #include "q4_internal.h"
 using namespace q4;
+
+static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, const TransformerWeights* w) {
+    const int dim = p->dim, hidden = p->hidden_dim;
+    const int head_size = dim / p->n_heads;
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    const PerLayerWeight* L = &w->layers[i % w->num_layers];   // ring: a different layer's weights every launch
+    const int loff = (i % w->num_layers) * p->seq_len * kv_dim;
+    switch (kernel_id) {
+        case 0: return launch_ffn_fused(s->hb, s->x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden);
+        case 1: return q4_matmul_q4(s->hb, s->xb, &L->wq_gate, dim, hidden, 0, -1, nullptr);
+        case 2: return q4_matmul_q4(s->xb, s->hb, &L->wq_down, hidden, dim, 1, -1, nullptr);
+        case 3: return launch_qkv_fused(s->q, s->key_cache, s->value_cache, s->x, L->rms_att_weight, &L->wq_q, &L->wq_k,
+                                        &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta);
+        case 4: return q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr);
+        case 5: return q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f);
+        case 6: return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
+                                        p->n_heads / p->n_kv_heads, p->seq_len, s->pos, p->seq_len);
+        case 7: return q4_rmsnorm(s->xb, s->x, w->rms_final_weight, dim);
+        case 8: return q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 0);
+        case 9: return q4_copy_embedding(s->x, w->token_embedding_table, dim, s->shared_data->tokens, s->pos);
+    }
+    return Q4_ERR_ARG;
+}
+
+// Steady-state cost of one launch INSIDE a hipGraph (what the decode loop pays: kernel + boundary): `iters` launches
+// of kernel_id over the ring of layers are captured into one graph, replayed `reps` times; returns microseconds per
+// launch from the wall clock around the replays (after one warm replay). <0 on error.
+extern "C" double q4_bench_kernel_graph(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
+                                        int reps) {
+    if (iters < 1 || reps < 1 || !g_stream) return -1.0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal) != hipSuccess) return -1.0;
+    int rc = 0;
+    for (int i = 0; i < iters && !rc; i++) rc = launch_by_id(kernel_id, i, p, s, w);
+    if (hipStreamEndCapture(g_stream, &graph) != hipSuccess || rc) { if (graph) hipGraphDestroy(graph); return -1.0; }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(graph); return -1.0; }
+    hipGraphDestroy(graph);
+    double us = -1.0;
+    if (hipGraphLaunch(exec, g_stream) == hipSuccess && hipStreamSynchronize(g_stream) == hipSuccess) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        bool ok = true;
+        for (int r = 0; r < reps && ok; r++) ok = hipGraphLaunch(exec, g_stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(g_stream) == hipSuccess;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (ok) us = ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3) / ((double)iters * reps);
+    }
+    hipGraphExecDestroy(exec);
+    return us;
+}
 
 extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
                                   double* min_us, double* max_us) {

@@ -14,8 +14,9 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 // launch shapes (columns per wave, waves per block); tuned on MI355X, see DESIGN.md
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
 int g_ablate = 0;
+int g_ksplit = 1;
 unsigned long long* g_dbg = nullptr;
-static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {4, 4}, {4, 4}, {4, 4}};
+static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {4, 4}, {4, 4}, {2, 4}};
 
 // ------------------------------------------------------------------------------------------------
 // rmsnorm_kernel (gpu_kernels.h:72-105). One block; 16-byte loads; the canonical chunk-partial reduction
@@ -284,9 +285,23 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
     __shared__ float sval[16];
     __shared__ int sidx[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the position lives in HBM too (pPosGpu == *pPos by construction, :490-491): read that copy instead of
+    // paying a PCIe round trip to the pinned host word on every token
+    int token_pos = *pPosGpu;
     float max_val = -INFINITY;
     int max_pos = 0x7fffffff;
-    for (int i = tid; i < size; i += blockDim.x) {
+    const int n8 = size >> 3;
+    for (int u = tid; u < n8; u += blockDim.x) {              // 16-byte loads, first max wins inside a thread
+        const u32x4 v = reinterpret_cast<const u32x4*>(x)[u];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const h2 p = as_h2(v[e]);
+            const float a = (float)p.x, b = (float)p.y;
+            if (a > max_val) { max_val = a; max_pos = u * 8 + 2 * e; }
+            if (b > max_val) { max_val = b; max_pos = u * 8 + 2 * e + 1; }
+        }
+    }
+    for (int i = n8 * 8 + tid; i < size; i += blockDim.x) {
         const float v = h2f(x[i]);
         if (v > max_val) { max_val = v; max_pos = i; }
     }
@@ -304,7 +319,6 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
         for (int w = 1; w < nw; w++)
             if (sval[w] > max_val || (sval[w] == max_val && sidx[w] < max_pos)) { max_val = sval[w]; max_pos = sidx[w]; }
         if (max_pos == 0x7fffffff) max_pos = 0;          // all NaN / -inf
-        int token_pos = *pPos;
         token_pos++;
         if (write_token) result[token_pos] = max_pos;    // :486-487
         *pPos = token_pos;                               // :490 (unblocks the CPU)
@@ -396,6 +410,7 @@ using namespace q4;
 extern "C" {
 
 void q4_set_ablate(int mode) { g_ablate = mode; }
+void q4_set_ksplit(int on) { g_ksplit = on; }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 
 void q4_set_gemv_tune(int kind, int cols, int waves) {

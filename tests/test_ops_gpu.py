@@ -98,7 +98,7 @@ def test_argmax(q4, orc, rng, size):
     x[[5, size - 3]] = x.max() + np.float16(1)     # a tie: lowest index must win
     dx = q4.DevBuf(x)
     ring = q4.DevBuf(np.zeros(16, dtype=np.int32))
-    hpos, dpos = q4.DevBuf(np.array([4], dtype=np.int32)), q4.DevBuf(np.array([0], dtype=np.int32))
+    hpos, dpos = q4.DevBuf(np.array([4], dtype=np.int32)), q4.DevBuf(np.array([4], dtype=np.int32))   # host + device copies of pos
     q4.check(q4.lib().q4_argmax(dx.ptr, size, ring.ptr, hpos.ptr, dpos.ptr, 1))
     q4.synchronize()
     assert orc.argmax(x) == 5

@@ -89,5 +89,15 @@ int main() {
     }
     STREAM(8, 256, 256) STREAM(8, 1024, 256) STREAM(8, 1376, 256) STREAM(8, 2752, 256) STREAM(16, 1376, 256) STREAM(8, 5504, 256)
     STREAM(16, 2752, 256) STREAM(8, 688, 512) STREAM(32, 688, 256) STREAM(8, 16000, 256) STREAM(16, 8000, 256) STREAM(2, 5504, 256) STREAM(4, 2752, 256)
+    // Infinity Cache (MALL) residency: re-stream the SAME buffer every launch (fits the 256 MiB LLC) vs the rotating ring
+#define SAME(N, G, T)                                                                                                       \
+    {                                                                                                                       \
+        size_t per = (size_t)(G) * ((T) / 64) * (N) * 1024;                                                                 \
+        char nm[64]; snprintf(nm, 64, "SAME-BUFFER %d KiB/wave grid %d (%.1f MB)", N, G, per / 1e6);                          \
+        timeit(nm, [&](hipEvent_t a, hipEvent_t b) {                                                                        \
+            if (a) hipExtLaunchKernelGGL((k_stream<N>), dim3(G), dim3(T), 0, s, a, b, 0, (const u4*)src, out, (size_t)(N) * 64); \
+            else hipLaunchKernelGGL((k_stream<N>), dim3(G), dim3(T), 0, s, (const u4*)src, out, (size_t)(N) * 64); }, 100, per); \
+    }
+    SAME(8, 1376, 256) SAME(8, 2752, 256) SAME(8, 5504, 256) SAME(8, 256, 256)
     return 0;
 }
