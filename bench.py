@@ -145,9 +145,15 @@ def main():
             avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
             kernels[name] = {"us": round(avg, 3), "min_us": round(mn, 3), "bytes": nbytes, "GBps": round(nbytes / avg / 1e3, 1)}
         dom = kernels[kb[0][0]]
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC passes need rocprofv3 around the process:
+        if os.path.exists(tpath) and args.model == "7b":              # measured separately, committed with its CSVs
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         roofline = {"bound": "hbm", "kernel": kb[0][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"]}
+                    "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"],
+                    "graph_us_per_launch": round(tr.bench_kernel_graph(0, 32, 20), 3)}
         int4_bytes = sum(kb[k][1] for k in (0, 2, 3, 4))
         int4_us = sum(kernels[kb[k][0]]["us"] for k in (0, 2, 3, 4))
         kernels["int4_gemv_all_per_layer"] = {"us": round(int4_us, 3), "bytes": int4_bytes, "GBps": round(int4_bytes / int4_us / 1e3, 1)}

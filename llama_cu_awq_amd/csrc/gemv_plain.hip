@@ -4,7 +4,7 @@ namespace q4 {
 int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
 #define Q4_CASE(S, C) if (slots == S && cols == C) return launch_one<MODE_PLAIN, S, C, false>(a, waves);
     const int slots = pick_slots(a.nslots);
-    if (g_ksplit && slots > 0) {   // two waves per column group (see gemv_q4.h, KS)
+    if (g_ksplit && slots > 0 && a.nslots >= 5) {   // long-K (down projection): two waves per column group (gemv_q4.h, KS)
         const int sh = (a.nslots + 1) / 2;
 #define Q4_KS(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 2>(a, waves);
         Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4)
