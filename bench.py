@@ -71,27 +71,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_dist
 
+    # N > 1: torch (its bundled HIP runtime) must be initialised BEFORE libllama2_q4.so is loaded -- both export
+    # libamdhip64.so.7 and the first one loaded serves the whole process; loading ours first leaves torch.cuda
+    # with "No HIP GPUs are available". With torch first, the library binds to the runtime torch already loaded.
+    dist = None
+    dist_device = "cpu"
+    if use_dist:
+        import torch
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        from llama_cu_awq_amd import replicas
+        try:
+            torch.cuda.set_device(local_rank)
+            dist = replicas.init("nccl", rank, world)   # nccl == RCCL on ROCm; barrier + two scalar reductions only
+            dist_device = "cuda"
+            dist.all_reduce(torch.zeros(1, device="cuda"))
+            torch.cuda.synchronize()
+        except Exception as e:                           # no usable torch.cuda: the replicas still only need a barrier
+            sys.stderr.write("bench: RCCL init failed (%s); using gloo for the barrier\n" % e)
+            dist = replicas.init("gloo", rank, world)
+            dist_device = "cpu"
+
     from llama_cu_awq_amd import api, synth, replicas   # raises if libllama2_q4.so is missing: no fallback
     L = api.lib()
     api.check(L.q4_set_device(local_rank if world > 1 else 0))
     if args.no_graphs:
         L.q4_set_use_graphs(0)
 
-    dist = None
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist = replicas.init("nccl", rank, world)   # nccl == RCCL on ROCm; barrier + two scalar reductions only
-
     def barrier():
         api.check(L.q4_device_synchronize())
         if use_dist:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist_device == "cuda":
+                import torch
+                torch.cuda.synchronize()
 
     # ---- synthetic checkpoint (rank 0 writes, everyone loads) --------------------------------------
     geom = synth.GEOMETRIES[args.model]
@@ -132,7 +145,7 @@ def main():
             tokens0 = toks
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, total_tokens = replicas.aggregate(elapsed, timed_tokens, dist if use_dist else None, device="cuda")
+    elapsed, total_tokens = replicas.aggregate(elapsed, timed_tokens, dist if use_dist else None, device=dist_device)
     value = total_tokens / elapsed
 
     # ---- per-kernel durations (dispatch timestamps, ring over the layers' weights) ------------------
