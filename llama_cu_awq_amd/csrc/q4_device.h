@@ -64,15 +64,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // streamed-once weights: non-temporal 128-bit load (global_load_dwordx4 ... nt)
 __device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
-// sum of squares of 8 packed halves, sequential fma chain (canonical order for rmsnorm)
+// sum of squares of 8 packed halves: four v_dot2c_f32_f16 (x.x*x.x + x.y*x.y + acc, fp32) in element order -- the
+// canonical per-chunk order of every rmsnorm in this library (stand-alone kernel and fused staging share this function)
 __device__ __forceinline__ float sumsq8(u32x4 v, float acc) {
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        h2 p = as_h2(v[d]);
-        float a = (float)p.x, b = (float)p.y;
-        acc = __builtin_fmaf(a, a, acc);
-        acc = __builtin_fmaf(b, b, acc);
-    }
+    for (int d = 0; d < 4; d++) acc = __builtin_amdgcn_fdot2(as_h2(v[d]), as_h2(v[d]), acc, false);
     return acc;
 }
 
@@ -111,15 +107,21 @@ __device__ __forceinline__ void rope_angle(int i, int head_size, int pos, float 
 }
 
 // normalise 8 halves: half(x * (ss * w))   gpu_kernels.h:100-102
+// Mixed-precision FMAs read the fp16 halves directly (no v_cvt) and round the fp32 product once to fp16:
+//   t = ss * float(w)            v_fma_mix_f32      (fp32)
+//   r = half(float(x) * t)       v_fma_mixlo/hi_f16 (fp32 product, one rounding to fp16) == the reference's arithmetic
+// 4 VALU per pair instead of the 7 hipcc emits for the C expression (cvt x2, cvt w2, 2 pk_mul, cvt_pk).
 __device__ __forceinline__ u32x4 rms_apply8(u32x4 xv, u32x4 wv, float ss) {
     u32x4 o;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        h2 x = as_h2(xv[d]), w = as_h2(wv[d]);
-        h2 r;
-        r.x = (f16_t)((float)x.x * (ss * (float)w.x));
-        r.y = (f16_t)((float)x.y * (ss * (float)w.y));
-        o[d] = as_u(r);
+        float tl, th;
+        unsigned r;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(tl) : "v"(wv[d]), "v"(ss));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(th) : "v"(wv[d]), "v"(ss));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(xv[d]), "v"(tl));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(xv[d]), "v"(th));
+        o[d] = r;
     }
     return o;
 }

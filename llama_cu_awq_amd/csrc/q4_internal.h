@@ -66,7 +66,8 @@ int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, con
                      const int* pPos, int head_size, float rope_theta);
 int rope_table_build(int seq_len, int head_size, float theta);   // (cos,sin) table for the fused QKV epilogue
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                     int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, int kv_rows);
+                     int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
+                     size_t scratch_bytes);
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
                      int dim, int hidden);
 

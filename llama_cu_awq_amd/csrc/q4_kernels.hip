@@ -259,6 +259,128 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
     }
 }
 
+// Long contexts: the same block, but one per (head, 256-position chunk) so that all CUs pull on the KV cache (at
+// pos 2047 a layer's K+V is 32 MB; 32 single-head blocks would stream it at a few CUs' worth of bandwidth). Each
+// block leaves flash-decode partials -- running max m, sum l of exp(s - m), un-normalised acc[head_size] in fp32 --
+// in the `att` scratch (RunState::att, the buffer the reference keeps its scores in); attention_combine_kernel merges
+// them: out = sum_s exp(m_s - M) acc_s / sum_s exp(m_s - M) l_s. Scores are still rounded through fp16 (:167);
+// the probabilities stay fp32 here (the reference rounds them to fp16, :400 -- a <= 2^-11 relative difference).
+constexpr int ATT_CHUNK = 256;
+template <int LPR>
+__global__ void __launch_bounds__(ATT_NW * 64) attention_split_kernel(float* partials, const q4_half* q, const q4_half* key_cache,
+                                                                      const q4_half* value_cache, int head_size, int kv_mul,
+                                                                      int kv_dim, const int* pPos, float alpha) {
+    constexpr int R = 64 / LPR, U = 4, NW = ATT_NW;
+    constexpr int stride = NW * R;
+    static_assert(stride * U == ATT_CHUNK, "one chunk = one register-resident group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red_max = reinterpret_cast<float*>(smem);
+    float* red_sum = red_max + 16;
+    float* outp = red_sum + 16;                              // [NW][head_size]
+    const int h = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = tid >> 6;
+    const int row = lane / LPR, sub = lane % LPR;
+    const int size = *pPos + 1;
+    const int t_base = sp * ATT_CHUNK;
+    float* my = partials + ((size_t)h * nsp + sp) * (head_size + 2);
+    if (t_base >= size) {                                    // chunk entirely in the future: neutral partial
+        if (tid == 0) { my[0] = -INFINITY; my[1] = 0.f; }
+        return;
+    }
+    const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    u32x4 kv[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = t_base + wave * R + row + u * stride;
+        const int tc = t < size ? t : size - 1;
+        kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+        vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+    }
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
+    float sc[U];
+    float wmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = t_base + wave * R + row + u * stride;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
+        s = row_sum<LPR>(s);
+        s = round_h(s * alpha);
+        sc[u] = t < size ? s : -INFINITY;
+        wmax = fmaxf(wmax, sc[u]);
+    }
+    wmax = wave_max(wmax);
+    if (lane == 0) red_max[wave] = wmax;
+    __syncthreads();
+    const float m = row16_max(red_max[lane & 15]);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const float p = expf(sc[u] - m);                     // 0 for masked positions (sc = -inf)
+        if (sub == 0) lsum += p;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const h2 v2 = as_h2(vv[u][e]);
+            acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);
+            acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_sum[wave] = lsum;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v = acc[e];
+        if (LPR <= 32) v += __shfl_xor(v, 32);
+        if (LPR <= 16) v += __shfl_xor(v, 16);
+        if (LPR <= 8) v += __shfl_xor(v, 8);
+        if (LPR <= 4) v += __shfl_xor(v, 4);
+        acc[e] = v;
+    }
+    if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    const float l = row16_sum(red_sum[lane & 15]);
+    if (tid == 0) { my[0] = m; my[1] = l; }
+    for (int n = tid; n < head_size; n += NW * 64) {
+        float part[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += part[w];
+        my[2 + n] = s;
+    }
+}
+
+__global__ void attention_combine_kernel(q4_half* output, const float* partials, int head_size, int nsp) {
+    const int h = blockIdx.x;
+    const float* base = partials + (size_t)h * nsp * (head_size + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < nsp; s++) M = fmaxf(M, base[(size_t)s * (head_size + 2)]);
+    float denom = 0.f;
+    for (int s = 0; s < nsp; s++) {
+        const float* ps = base + (size_t)s * (head_size + 2);
+        denom += ps[1] * expf(ps[0] - M);                   // fixed order over chunks
+    }
+    for (int n = threadIdx.x; n < head_size; n += blockDim.x) {
+        float num = 0.f;
+        for (int s = 0; s < nsp; s++) {
+            const float* ps = base + (size_t)s * (head_size + 2);
+            const float w = expf(ps[0] - M);
+            num += w > 0.f ? ps[2 + n] * w : 0.f;           // neutral chunks hold no acc
+        }
+        output[(size_t)h * head_size + n] = f2h(num / denom);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // copy_embedding_kernel (gpu_kernels.h:61-69); 16-byte copies. tokens may live in mapped host memory.
 __global__ void copy_embedding_kernel(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {
@@ -484,15 +606,28 @@ int q4_rope_rotation(q4_half* q, q4_half* k, int num_heads, int num_kv_heads, in
 
 namespace q4 {
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                     int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, int kv_rows) {
-    (void)kv_rows;
+                     int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
+                     size_t scratch_bytes) {
     const int dim = head_size * num_heads;
     const int kv_dim = dim / kv_mul;
     const float alpha = (float)(1.0 / sqrt((double)head_size));                     // llama2_q4.cu:273
+    dim3 block(ATT_NW * 64);
+    // long context: one block per (head, 256-position chunk) + a combine kernel (see attention_split_kernel)
+    const int nsp = divUp(max_seq_len, ATT_CHUNK);
+    const bool split = max_seq_len >= 1024 && scratch != nullptr && head_size == 128 &&
+                       (size_t)num_heads * nsp * (head_size + 2) * sizeof(float) <= scratch_bytes;
+    if (split) {
+        const size_t smem = (size_t)(32 + ATT_NW * head_size) * 4;
+        Q4_LAUNCH((attention_split_kernel<16>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
+                  head_size, kv_mul, kv_dim, pPos, alpha);
+        Q4_LAUNCH(attention_combine_kernel, dim3(num_heads), dim3(128), 0, output, (const float*)scratch, head_size, nsp);
+        Q4_LAUNCH_CHECK();
+        return Q4_OK;
+    }
     // LDS: 32 reduction floats + NW*head_size output partials + one fp32 score per position
     const size_t smem = (size_t)(32 + ATT_NW * head_size + max_seq_len) * 4;
     if (smem > 160 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;                          // > ~38K positions
-    dim3 grid(num_heads), block(ATT_NW * 64);
+    dim3 grid(num_heads);
 #define Q4_ATT(L)                                                                                                  \
     {                                                                                                              \
         if (smem > 64 * 1024)                                                                                      \
@@ -518,8 +653,10 @@ extern "C" {
 
 int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                             q4_half* att, int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos) {
-    (void)att;
-    return launch_attention(output, q, key_cache, value_cache, num_heads, head_size, kv_mul, max_seq_len, pPos, 0);
+    // `att` (n_heads * max_seq_len halves in the reference) doubles as the split-context scratch when it is big enough
+    const size_t att_bytes = att ? (size_t)num_heads * max_seq_len * sizeof(q4_half) : 0;
+    return launch_attention(output, q, key_cache, value_cache, num_heads, head_size, kv_mul, max_seq_len, pPos, (float*)att,
+                            att_bytes);
 }
 
 int q4_copy_embedding(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {

@@ -370,7 +370,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache, p->n_heads, p->n_kv_heads, head_size, pPos, loff, p->rope_theta));   // :317
         }
         Q4_TRY(launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
-                                seq_len_bin, pPos, g_fusion ? p->seq_len : 0));                         // :320
+                                seq_len_bin, pPos, (float*)s->att,
+                                (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half)));   // :320
         Q4_TRY(q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                         // :323
         if (g_fusion) {
             Q4_TRY(launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329

@@ -77,6 +77,25 @@ def test_attention(q4, orc, rng, heads, kv_mul, hs, pos, seq):
     assert (d > 2).mean() < 0.02, (d > 2).mean()
 
 
+@pytest.mark.parametrize("pos,seq", [(2047, 2048), (1000, 2048), (100, 1024), (1023, 1024), (4000, 4096)])
+def test_attention_split_context(q4, orc, rng, pos, seq):
+    """Long-context path: one block per (head, 256-position chunk) + combine, scratch = the `att` buffer."""
+    heads, hs, kv_mul = 32, 128, 1
+    dim = heads * hs
+    q = rng.standard_normal(dim).astype(np.float16)
+    kc = rng.standard_normal(seq * dim).astype(np.float16)
+    vc = rng.standard_normal(seq * dim).astype(np.float16)
+    ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos)
+    dq, dk, dv, do = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(vc), q4.DevBuf(nbytes=dim * 2)
+    att = q4.DevBuf(nbytes=heads * max(seq, dim) * 2 * 2)
+    dpos = q4.DevBuf(np.array([pos], dtype=np.int32))
+    q4.check(q4.lib().q4_multi_head_attention(do.ptr, dq.ptr, dk.ptr, dv.ptr, att.ptr, heads, hs, kv_mul, seq * 2 if seq < 4096 else seq, dpos.ptr))
+    q4.synchronize()
+    got = do.get(np.float16, dim)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), err.max()
+
+
 def test_copy_embedding_and_convert(q4, rng):
     size, vocab = 4096, 64
     table = rng.standard_normal(vocab * size).astype(np.float16)
