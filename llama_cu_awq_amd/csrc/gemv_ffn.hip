@@ -9,6 +9,7 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves) {
         if (g_ablate == 1) return launch_one<MODE_FFN, 2, 2, true, 1>(a, waves);
         if (g_ablate == 2) return launch_one<MODE_FFN, 2, 2, true, 2>(a, waves);
         if (g_ablate == 3) return launch_one<MODE_FFN, 2, 2, true, 3>(a, waves);
+        if (g_ablate == 4) return launch_one<MODE_FFN, 2, 2, true, 4>(a, waves);
     }
     if (cols != 2 && cols != 4) cols = 2;
     if (slots >= 4 && cols == 4) cols = 2;   // gate+up doubles the loads in flight

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
     if (ABL == 3) ts[1] = __builtin_readcyclecounter();
     // ---- 3. stage the activation vector into LDS, optional fused rmsnorm -----------------------
-    {
+    if (ABL != 4) {   // (ABL 4: no staging at all, garbage x -- measures the kernel without the x chain)
         float ss = 1.f;
         if (NORM) {
 #pragma unroll

@@ -52,10 +52,10 @@ for kid in (0, 3):
             except Exception as e:
                 print("kernel %d cols %d waves %d failed: %s" % (kid, cols, waves, e))
 L.q4_set_gemv_tune(3, 2, 4)
-for abl in (0, 1, 2):
+for abl in (0, 1, 2, 4):
     L.q4_set_ablate(abl)
     avg, mn, gbs = run(0)
-    print("ablate %d (0 product, 1 loads only, 2 math only) ffn 2x2: %7.2f us (min %6.2f) %7.1f GB/s" % (abl, avg, mn, gbs), flush=True)
+    print("ablate %d (0 product, 1 loads only, 2 math only, 4 no x staging) ffn 2x2: %7.2f us (min %6.2f) %7.1f GB/s" % (abl, avg, mn, gbs), flush=True)
 L.q4_set_ablate(0)
 for kid, nm in ((6, "attention"), (7, "rmsnorm"), (8, "argmax"), (9, "embedding")):
     print("%-10s graph %.2f us per launch" % (nm, tr.bench_kernel_graph(kid, 32, 20)))
