@@ -128,10 +128,13 @@ constexpr int ATT_NW = 16;   // waves per attention block (one block per head)
 template <int LPR>
 __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
                                                                 const q4_half* value_cache, int head_size, int kv_mul,
-                                                                int kv_dim, const int* pPos, float alpha, int lds_scores) {
+                                                                int kv_dim, const int* pPos, float alpha, int lds_scores,
+                                                                unsigned long long* dbg) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr int U = 4;                   // wave instructions in flight per pass
     constexpr int NW = ATT_NW;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
+    if (dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red_max = reinterpret_cast<float*>(smem);         // [16]
     float* red_sum = red_max + 16;                           // [16]
@@ -146,6 +149,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
     const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
     const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
     const int size = *pPos + 1;
+    if (dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
     // context <= `group` positions (rows are clamped to pos, so only cache-warm rows are touched)
@@ -188,8 +192,10 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
         }
     }
     wmax = wave_max(wmax);
+    if (dbg) ts[2] = __builtin_readcyclecounter();
     if (lane == 0) red_max[wave] = wmax;
     __syncthreads();                                                              // barrier 1: scores + wave maxima
+    if (dbg) ts[3] = __builtin_readcyclecounter();
 
     // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
     const float m = row16_max(red_max[lane & 15]);
@@ -202,8 +208,10 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
     sum = wave_sum(sum);
     if (lane == 0) red_sum[wave] = sum;
     __syncthreads();                                                              // barrier 2: exps + wave sums
+    if (dbg) ts[4] = __builtin_readcyclecounter();
     // fixed order: DPP tree over the 16 wave sums
     sum = row16_sum(red_sum[lane & 15]);
+    const float inv_sum = 1.0f / sum;       // one IEEE division; p = e * inv_sum is within 1 fp32 ulp of e / sum (:400)
 
     // ---- pass 2: att . V -----------------------------------------------------------------------------
     float acc[8];
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = g0 + wave * R + row + u * stride;
-            const float p = t < size ? round_h(sc[t] / sum) : 0.f;                // gpu_kernels.h:400
+            const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const h2 v2 = as_h2(vv[u][e]);
@@ -233,20 +241,30 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
             }
         }
     }
-    // combine the R rows of a wave (shuffle across row groups), then the waves through LDS
+    // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
+    // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
+    // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
+    if constexpr (LPR == 16) {
+        const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
+        const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
+        outp[wave * head_size + sub * 8 + row] = s0;
+        outp[wave * head_size + sub * 8 + 4 + row] = s1;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float v = acc[e];
-        if (LPR <= 32) v += __shfl_xor(v, 32);
-        if (LPR <= 16) v += __shfl_xor(v, 16);
-        if (LPR <= 8) v += __shfl_xor(v, 8);
-        if (LPR <= 4) v += __shfl_xor(v, 4);
-        acc[e] = v;
-    }
-    if (lane < LPR) {
+        for (int e = 0; e < 8; e++) {
+            float v = acc[e];
+            if (LPR <= 32) v += __shfl_xor(v, 32);
+            if (LPR <= 16) v += __shfl_xor(v, 16);
+            if (LPR <= 8) v += __shfl_xor(v, 8);
+            if (LPR <= 4) v += __shfl_xor(v, 4);
+            acc[e] = v;
+        }
+        if (lane < LPR) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+        }
     }
+    if (dbg) ts[5] = __builtin_readcyclecounter();
     __syncthreads();                                                              // barrier 3: output partials
     for (int n = tid; n < head_size; n += NW * 64) {
         float part[NW];
@@ -256,6 +274,12 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
 #pragma unroll
         for (int w = 0; w < NW; w++) s += part[w];
         output[(size_t)h * head_size + n] = f2h(s);
+    }
+    if (dbg && lane == 0) {
+        ts[6] = __builtin_readcyclecounter();
+        unsigned long long* d = dbg + ((size_t)h * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = ts[i];
     }
 }
 
@@ -634,7 +658,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
             Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                \
         Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache, head_size, kv_mul,  \
-                  kv_dim, pPos, alpha, max_seq_len);                                                               \
+                  kv_dim, pPos, alpha, max_seq_len, g_dbg);                                                        \
     }
     switch (head_size) {
         case 32: Q4_ATT(4) break;
