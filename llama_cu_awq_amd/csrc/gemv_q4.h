@@ -13,14 +13,15 @@
 //  * the activation vector is staged once per block into LDS, pre-permuted so that the 16 B a lane needs for
 //    weight dword d are one conflict-free ds_read_b128: unit [(slot*4 + d)*64 + lane] holds (x0,x4),(x1,x5),
 //    (x2,x6),(x3,x7) of the 8 inputs that dword multiplies.
-//  * dequant without converts or subtracts -- the kernel is VALU-bound if written naively (measured: v_and_or,
-//    v_dot2c, v_pk_* all issue at half rate, ~1.8 ns per wave instruction per SIMD):
-//      (w & 0x000F000F) | 0x64006400 is the half2 (1024+q_i, 1024+q_{i+4}); the odd nibbles sit 4 bits higher,
-//      i.e. (1024+16 q). v_dot2c_f32_f16 accumulates them against x in two fp32 accumulators:
-//         acc_e = 1024*Se + sum_even q x        acc_o = 1024*So + 16 * sum_odd q x
-//      and per 32 weights  sum (q-z) x = acc_e + acc_o/16 - (1024 Se + 64 So) - z (Se + So), where the two
-//      x-only terms are computed once per block during staging. 9 VALU per 8 weights instead of 13, fp32 error
-//      ~2^-24 * 1024 * |x| per term (far below one fp16 ulp of the output).
+//  * dequant without converts, subtracts or magic exponents -- the kernel is VALU-bound if written naively (measured:
+//    v_and_or, v_dot2c, v_pk_*, v_cvt_* issue at half rate, ~1.8 ns per wave instruction per SIMD; plain VOP2 integer
+//    ops at full rate): a nibble left in place IS an fp16 denormal, (w & 0x000F000F) = the half2 (q_i, q_{i+4}) * 2^-24,
+//    and v_dot2c_f32_f16 multiplies denormal inputs exactly (verified on gfx950, tools/t_denorm.hip). The odd nibbles
+//    sit 4 bits higher (16 q * 2^-24). Two fp32 accumulators, acc_e and acc_o, then
+//        sum_k q x = 2^20 (16 acc_e + acc_o),      sum_k (q - z) x = that - z * (sum of the 32 x)
+//    with the x-only sum computed once per block at staging and the 2^20 applied once per column at the end (all
+//    power-of-two scalings are exact). 1 shift + 4 v_and_b32 (full rate) + 4 v_dot2c per 8 weights; products are
+//    exact in fp32 (4 x 11 bits), so the arithmetic is as accurate as the reference's (q - z) * s * x in fp32.
 //  * cross-lane reduction transposes while it reduces (v_permlane32_swap, v_permlane16_swap, DPP row ops):
 //    4 (8) column sums cost 10 (20) VALU instead of 44 (88), and leave column r's total in DPP row r, so the
 //    epilogue (residual add / SiLU / RoPE) runs once for all columns in parallel lanes.
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     constexpr int NUNITS = TS * 256;            // 16-byte LDS units (zero padded past K)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem);                                   // [SLOTS][4][64] permuted x
-    float2* sx = reinterpret_cast<float2*>(smem + (size_t)NUNITS * 16);           // [SLOTS][64] (-(1024Se+64So), -(Se+So))
+    float* sx = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16);             // [TS][64] -(sum of the 32 x) * 2^-20
     float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16 + TS * 512);   // [NUNITS] chunk partials / K-split exchange
 
     const unsigned tid = threadIdx.x;
@@ -217,19 +218,15 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             if (NORM) v = rms_apply8(v, wraw[i], ss);
             if (u >= nchunks) v = (u32x4){0u, 0u, 0u, 0u};
             const u32x4 pv = permute_x8(v);
-            // x-only correction terms of the 32 inputs of uint4 j (4 consecutive units = one lane quad)
-            float se = __builtin_amdgcn_fdot2(as_h2(pv[0]), ones, 0.f, false);   // x0+x4
-            se = __builtin_amdgcn_fdot2(as_h2(pv[2]), ones, se, false);          // +x2+x6
-            float so = __builtin_amdgcn_fdot2(as_h2(pv[1]), ones, 0.f, false);   // x1+x5
-            so = __builtin_amdgcn_fdot2(as_h2(pv[3]), ones, so, false);          // +x3+x7
-            float ca = __builtin_fmaf(se, 1024.f, so * 64.f);
-            float cb = se + so;
-            ca += dpp_mov<0xB1>(ca); ca += dpp_mov<0x4E>(ca);   // quad sums (the 4 units of one uint4)
-            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+            // x-only term of the zero point: sum of the 32 inputs of uint4 j (4 consecutive units = one lane quad)
+            float cb = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum
             const unsigned j = u >> 2, d = u & 3u;
             if (u < NUNITS) {
                 xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
-                if (d == 0) sx[j] = make_float2(-ca, -cb);
+                if (d == 0) sx[j] = cb * -9.5367431640625e-07f;   // -(sum x) * 2^-20
             }
         }
         __syncthreads();
@@ -240,8 +237,6 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     for (int s = PRE; s < SLOTS; s++) Q4_ISSUE_SLOT(s)
 #undef Q4_ISSUE_SLOT
 
-    unsigned M0 = 0x000F000Fu, M1 = 0x00F000F0u, MG = 0x64006400u;
-    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MG));   // keep in VGPRs so (w & M) | MG selects v_and_or_b32
 
     // ---- 4. consume in issue order -------------------------------------------------------------
     float colsum[NMAT][COLS];
@@ -255,7 +250,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         u32x4 X[4];
 #pragma unroll
         for (int d = 0; d < 4; d++) X[d] = xs[(((sbase + s) * 4 + d) << 6) + lane];
-        const float2 corr = sx[(sbase + s) * 64 + lane];
+        const float corr = sx[(sbase + s) * 64 + lane];
         const unsigned j = (sbase + s) * 64 + lane;
         const unsigned zsh = ((j >> 2) & 7u) * 4u;
 #pragma unroll
@@ -268,19 +263,19 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
                     t = as_f(((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x007FFFFFu) | 0x3F000000u) + as_f(X[s & 3][c & 3] & 0x3FFFFFFFu);
                 } else {
                     const u32x4 w = W[m][s][c];
-                    float acc_e = corr.x, acc_o = 0.f;
+                    float acc_e = 0.f, acc_o = 0.f;
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
                         const unsigned ww = w[d];
                         const unsigned tt = ww >> 8;
-                        acc_e = __builtin_amdgcn_fdot2(as_h2((ww & M0) | MG), as_h2(X[d][0]), acc_e, false);   // (n0,n4)
-                        acc_o = __builtin_amdgcn_fdot2(as_h2((ww & M1) | MG), as_h2(X[d][1]), acc_o, false);   // (n1,n5) x16
-                        acc_e = __builtin_amdgcn_fdot2(as_h2((tt & M0) | MG), as_h2(X[d][2]), acc_e, false);   // (n2,n6)
-                        acc_o = __builtin_amdgcn_fdot2(as_h2((tt & M1) | MG), as_h2(X[d][3]), acc_o, false);   // (n3,n7) x16
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[d][0]), acc_e, false);   // (n0,n4) * 2^-24
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[d][1]), acc_o, false);   // (n1,n5) * 2^-20
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][2]), acc_e, false);   // (n2,n6)
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][3]), acc_o, false);   // (n3,n7)
                     }
                     const float zf = (float)((ZW[m][s][c] >> zsh) & 0xFu);
-                    t = __builtin_fmaf(acc_o, 0.0625f, acc_e);
-                    t = __builtin_fmaf(zf, corr.y, t);
+                    t = __builtin_fmaf(acc_e, 16.f, acc_o);          // 2^-20 * sum q x
+                    t = __builtin_fmaf(zf, corr, t);                 // - z * 2^-20 * sum x
                 }
                 // idle tail lanes (j >= pw4) multiply re-read weights by the zero padding of xs/sx: exactly 0
                 colsum[m][c] = __builtin_fmaf(h2f(SC[m][s][c]), t, colsum[m][c]);
@@ -296,7 +291,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         q4_half* out = a.out[0];
         if (a.loff != -1) out += (size_t)a.loff + (size_t)(*a.pPos) * a.N;         // gpu_kernels.h:225-227
         if constexpr (COLS == 4) {
-            float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+            float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;   // 2^20, exact
             const int n = wg * 4 + row;
             if (KS == 2) {                      // fixed order: lower k half + upper k half
                 if (writer) part[wave * 4 + row] = tot;
@@ -309,8 +304,8 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
                 out[n] = f2h(r);                                                    // :231
             }
         } else {   // COLS == 8: row r holds columns 2r (w0) and 2r+1 (w1)
-            const float w0 = reduce4_rows(colsum[0][0], colsum[0][2], colsum[0][4], colsum[0][6]);
-            const float w1 = reduce4_rows(colsum[0][1], colsum[0][3], colsum[0][5], colsum[0][7]);
+            const float w0 = reduce4_rows(colsum[0][0], colsum[0][2], colsum[0][4], colsum[0][6]) * 1048576.f;
+            const float w1 = reduce4_rows(colsum[0][1], colsum[0][3], colsum[0][5], colsum[0][7]) * 1048576.f;
             const int n = wg * 8 + row * 2;
             if (writer && n < a.N) {
                 float r0 = w0, r1 = w1;
@@ -323,11 +318,11 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         float g, u;
         int n;
         if constexpr (COLS == 4) {        // row r: gate(col r) in g, up(col r) in u
-            g = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
-            u = reduce4_rows(colsum[NMAT - 1][0], colsum[NMAT - 1][1], colsum[NMAT - 1][2], colsum[NMAT - 1][3]);
+            g = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;
+            u = reduce4_rows(colsum[NMAT - 1][0], colsum[NMAT - 1][1], colsum[NMAT - 1][2], colsum[NMAT - 1][3]) * 1048576.f;
             n = wg * 4 + row;
         } else {                // COLS == 2: rows = gate c0, up c0, gate c1, up c1; fetch the partner row
-            const float w = reduce4_rows(colsum[0][0], colsum[NMAT - 1][0], colsum[0][1], colsum[NMAT - 1][1]);
+            const float w = reduce4_rows(colsum[0][0], colsum[NMAT - 1][0], colsum[0][1], colsum[NMAT - 1][1]) * 1048576.f;
             const float o = __shfl_xor(w, 16);
             g = (row & 1) ? o : w;
             u = (row & 1) ? w : o;
@@ -343,7 +338,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         int pos = 0;
         if (mat0 != 0 || a.rope) pos = *a.pPos;
         if (mat0 != 0) out += (size_t)a.loff + (size_t)pos * a.N;                   // gpu_kernels.h:251,253
-        const float mine = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]);
+        const float mine = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;
         const int hp = a.head_size >> 1;
         const int p = wg * 2 + (row & 1);                // pair index of this row
         const int head = p / hp, i = p - head * hp;
