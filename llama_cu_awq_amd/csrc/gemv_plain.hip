@@ -10,6 +10,10 @@ int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
         Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4)
 #undef Q4_KS
     }
+    if (cols == 4 && slots <= 3 && divUp(a.N, 4 * waves) <= 320) {   // about one block per CU: every load first
+        if (slots == 2) return launch_one<MODE_PLAIN, 2, 4, false, 5>(a, waves);
+        if (slots == 3) return launch_one<MODE_PLAIN, 3, 4, false, 5>(a, waves);
+    }
     if (cols != 4 && cols != 8) cols = 4;
     if (slots >= 4 && cols == 8) cols = 4;   // 8 columns x >= 4 uint4 per lane does not fit the register file
     Q4_CASE(2, 4) Q4_CASE(2, 8)

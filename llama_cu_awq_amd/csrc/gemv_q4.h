@@ -167,7 +167,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     // measured on MI355X (tools/sweep_gemv.py): for K <= 8192 staging FIRST wins (QKV 8.1 -> 7.4 us, gate 6.3 -> 5.7 us):
     // the x chain is short when no weight request is queued ahead of it; for the long-K down projection
     // (6-7 slots, 1 wave per SIMD) half of the loads in front of the staging hides it better (7.5 -> 7.2 us)
-    constexpr int PRE = SLOTS >= 6 ? (SLOTS + 1) / 2 : 0;
+    // ABL == 5 is not an ablation but the "all loads first" order: when the grid is about one block per CU (o-proj:
+    // 256 blocks) nothing else queues on the CU, so x chain and weight latency overlap (4.3 -> 4.0 us in-graph)
+    constexpr int PRE = ABL == 5 ? SLOTS : (SLOTS >= 6 ? (SLOTS + 1) / 2 : 0);
     u32x4 W[NMAT][SLOTS][COLS];
     unsigned ZW[NMAT][SLOTS][COLS];
     uint16_t SC[NMAT][SLOTS][COLS];
