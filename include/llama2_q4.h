@@ -202,6 +202,14 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
 int q4_run_transformer(int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
                        Sampler* pSampler);
 
+/* run_transformer with the position supplied by the caller (SharedData::pos is not read back), so that step pos+1
+ * can be queued while step pos runs; q4_wait_pos spins on SharedData::pos ("unblocks the CPU", gpu_kernels.h:490)
+ * until the device has published position >= pos. generate() uses the pair instead of cudaStreamSynchronize
+ * + run_transformer (llama2_q4.cu:468-470): same device order, no idle gap between tokens. */
+int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, const TransformerWeights* w,
+                          int copyLogits, Sampler* pSampler);
+int q4_wait_pos(const RunState* s, int pos);
+
 /* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1 (default): fused sequence
  * (rmsnorm folded into the consumer GEMV, RoPE + KV write in the QKV epilogue). Resets captured graphs. */
 void q4_set_fusion(int level);

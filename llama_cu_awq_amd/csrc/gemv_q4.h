@@ -27,6 +27,7 @@
 //    epilogue (residual add / SiLU / RoPE) runs once for all columns in parallel lanes.
 // No MFMA: 3.84 flop/B, the kernel is an HBM stream.
 #pragma once
+#include <type_traits>
 #include "q4_device.h"
 #include "q4_internal.h"
 
@@ -55,6 +56,7 @@ struct GemvArgs {
     float rope_theta;
     unsigned long long* dbg;   // ABL == 3 only: per-wave s_memtime stamps
     const float2* rope_table;  // [seq_len][head_size/2] (cos, sin) built with the reference's formula; null: compute
+    int early;                 // waves in the first `early` slots of a SIMD issue their weight loads before the staging ends
 };
 
 template <int MODE>
@@ -94,6 +96,12 @@ __device__ __forceinline__ float reduce4_rows(float v0, float v1, float v2, floa
 // without the weight loads.
 // register-heavy shapes (>= 24 uint4 in flight per lane, e.g. the 7B down projection) run 4 waves per block with
 // the whole 512-register file per lane; the others may use 8 waves per block
+// order in which the dispatcher filled this CU: HW_ID.wave_id (slot on the SIMD, [3:0]) major, simd_id ([5:4]) minor
+__device__ __forceinline__ int early_rank() {
+    const unsigned id = __builtin_amdgcn_s_getreg(10244);   // hwreg(HW_REG_HW_ID, 0, 6)
+    return (int)(((id & 15u) << 2) | (id >> 4));
+}
+
 template <int MODE, int SLOTS, int COLS>
 struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
 
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
     const int mat0 = (MODE == MODE_QKV) ? blockIdx.y : 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ABL == 3) ts[0] = __builtin_readcyclecounter();
+    if (ABL == 3) { ts[0] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }   // [6]: 100 MHz, same on every XCD
 
     // ---- column ownership ---------------------------------------------------------------------
     int col[COLS];
@@ -146,6 +154,13 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     int colc[COLS];   // clamped: loads stay in bounds, the store is skipped
 #pragma unroll
     for (int c = 0; c < COLS; c++) colc[c] = col[c] < a.N ? col[c] : a.N - 1;
+
+    // the position is fetched in front of everything else: hoisted next to its use, hipcc puts a vector load +
+    // vmcnt(0) between the weight loads and the first dot product, and the per-slot waits are gone
+    int pos_now = 0;
+    if (MODE == MODE_QKV) { if (mat0 != 0 || a.rope) pos_now = *a.pPos; }
+    else if (MODE == MODE_PLAIN) { if (a.loff != -1) pos_now = *a.pPos; }
+    asm volatile("" : "+v"(pos_now));
 
     // ---- 1. activation loads first: their wait (counted vmcnt) leaves the weight loads in flight ----
     u32x4 xraw[TS], wraw[TS];
@@ -200,13 +215,29 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
     if (ABL == 3) ts[1] = __builtin_readcyclecounter();
     // ---- 3. stage the activation vector into LDS, optional fused rmsnorm -----------------------
-    if (ABL != 4) {   // (ABL 4: no staging at all, garbage x -- measures the kernel without the x chain)
+    // Early birds: every wave of a launch enters within ~0.5 us and the CU's vector-memory path returns data in issue
+    // order, so normally the weight loads wait until x is staged (they would otherwise sit in front of other waves'
+    // x loads, or park this wave in issue back-pressure). The first `a.early` waves the dispatcher placed on the CU (HW_ID rank): once their own x has arrived (by then every other wave's x loads
+    // are queued too) they put their weight loads in flight and only then finish the staging, so HBM streams during
+    // the ~1.9 us x chain of the launch. Kept to ~64 KB per CU: those loads are accepted without back-pressure.
+    const bool early = ABL != 4 && ABL != 5 && PRE < SLOTS && a.early > 0 && early_rank() < a.early;
+    // (single load site in program order, the staging tail before OR after it: after a two-path join with loads on
+    // both sides hipcc's waitcnt pass falls back to vmcnt(0) and the progressive per-slot waits are lost)
+    float psum[TS];
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i < TS; i++) psum[i] = sumsq8(xraw[i], 0.f);
+        asm volatile("" ::"v"(psum[TS - 1]));           // x has arrived
+    } else {
+        asm volatile("" ::"v"(xraw[TS - 1]));
+    }
+    auto stage_tail = [&]() {
         float ss = 1.f;
         if (NORM) {
 #pragma unroll
             for (int i = 0; i < TS; i++) {
                 const unsigned u = tid + i * blockDim.x;
-                if (u < NUNITS) part[u] = u < nchunks ? sumsq8(xraw[i], 0.f) : 0.f;
+                if (u < NUNITS) part[u] = u < nchunks ? psum[i] : 0.f;
             }
             __syncthreads();
             if (ABL == 3) ts[2] = __builtin_readcyclecounter();
@@ -232,11 +263,14 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             }
         }
         __syncthreads();
-    }
-    if (ABL == 3) ts[3] = __builtin_readcyclecounter();
+        if (ABL == 3) ts[3] = __builtin_readcyclecounter();
+    };
+    if (ABL != 4 && !early) stage_tail();      // (ABL 4: no staging at all, garbage x -- the kernel without the x chain)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = PRE; s < SLOTS; s++) Q4_ISSUE_SLOT(s)
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 4 && early) stage_tail();
 #undef Q4_ISSUE_SLOT
 
 
@@ -291,7 +325,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
     if constexpr (MODE == MODE_PLAIN) {
         q4_half* out = a.out[0];
-        if (a.loff != -1) out += (size_t)a.loff + (size_t)(*a.pPos) * a.N;         // gpu_kernels.h:225-227
+        if (a.loff != -1) out += (size_t)a.loff + (size_t)pos_now * a.N;           // gpu_kernels.h:225-227
         if constexpr (COLS == 4) {
             float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;   // 2^20, exact
             const int n = wg * 4 + row;
@@ -337,8 +371,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         if (wr && n < a.N) a.out[0][n] = f2h(val);
     } else {   // MODE_QKV, COLS == 4: rows = pair0 first, pair1 first, pair0 second, pair1 second
         q4_half* out = a.out[mat0];
-        int pos = 0;
-        if (mat0 != 0 || a.rope) pos = *a.pPos;
+        const int pos = pos_now;
         if (mat0 != 0) out += (size_t)a.loff + (size_t)pos * a.N;                   // gpu_kernels.h:251,253
         const float mine = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;
         const int hp = a.head_size >> 1;

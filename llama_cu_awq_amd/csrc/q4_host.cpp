@@ -173,8 +173,10 @@ double q4_generate(Transformer* transformer, struct Tokenizer* tokenizer, Sample
     RunState* state = &transformer->state;
     die_on(q4_reset_sequence(state, prompt_tokens, num_prompt_tokens));            // :461-463
     while (pos < steps) {
-        die_on(q4_stream_synchronize());                                           // :468
-        die_on(q4_run_transformer(pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
+        // step `pos` is queued behind step pos-1 before the host waits for step pos-1's token (reference: sync, then
+        // launch, :468-470) -- same device order, the GPU never idles between tokens
+        die_on(q4_run_transformer_at(pos, pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
+        die_on(q4_wait_pos(state, pos));                                           // :468
         if (pos > 0) {
             next = q4_shared_token(state, pos);                                    // output token of the previous iteration
             if (next >= transformer->config.vocab_size) next = 0;                  // :474

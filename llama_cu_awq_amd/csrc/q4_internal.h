@@ -58,7 +58,7 @@ static inline QGeom make_geom(int K, int N) {
 }
 
 // ---- internal launchers shared by the API layer and the network (all enqueue on g_stream) ----
-struct GemvTune { int cols; int waves; };   // columns per wave, waves per block
+struct GemvTune { int cols; int waves; int early; };   // columns per wave, waves per block, early-bird wave slots per SIMD
 
 // fused layer kernels (validated against the unfused chain in tests/test_fusion_gpu.py)
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w,

@@ -16,7 +16,9 @@ enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUN
 int g_ablate = 0;
 int g_ksplit = 1;
 unsigned long long* g_dbg = nullptr;
-static GemvTune g_tune[TUNE_COUNT] = {{4, 4}, {4, 4}, {4, 4}, {2, 4}};
+// early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain; the
+// gate/up launch with 21 waves per CU gets slower with any early bird)
+static GemvTune g_tune[TUNE_COUNT] = {{4, 4, 4}, {4, 4, 4}, {4, 4, 4}, {2, 4, 0}};
 
 // ------------------------------------------------------------------------------------------------
 // rmsnorm_kernel (gpu_kernels.h:72-105). One block; 16-byte loads; the canonical chunk-partial reduction
@@ -467,9 +469,23 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
         if (max_pos == 0x7fffffff) max_pos = 0;          // all NaN / -inf
         token_pos++;
         if (write_token) result[token_pos] = max_pos;    // :486-487
+        __threadfence_system();                          // the host may be spinning on *pPos (q4_wait_pos)
         *pPos = token_pos;                               // :490 (unblocks the CPU)
         *pPosGpu = token_pos;                            // :491
     }
+}
+
+// L2 warm-up of a QWeight slice: block b touches one dword per 128-B line of the bytes the consumer GEMV's block b
+// will stream (blocks b of consecutive dispatches land on XCD b % 8 -- a speed-only hint, never a dependency).
+struct TouchArgs { const char* p[6]; unsigned bytes[6]; int n; };
+__global__ void __launch_bounds__(256) touch_lines_kernel(TouchArgs a, unsigned* sink) {
+    unsigned acc = 0;
+    for (int r = 0; r < a.n; r++) {
+        const char* base = a.p[r] + (size_t)blockIdx.x * a.bytes[r];
+        for (unsigned off = threadIdx.x * 128u; off < a.bytes[r]; off += 256u * 128u)
+            acc ^= *reinterpret_cast<const unsigned*>(base + off);
+    }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;      // keeps the loads alive, practically never taken
 }
 
 // (cos, sin) of every (position, pair) with the reference's own formula, so that table lookups in the fused QKV
@@ -533,6 +549,7 @@ int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, con
     a.x = x; a.rms_w = rms_w; a.pPos = pPos; a.loff = loff;
     a.rope = head_size > 0; a.head_size = head_size > 0 ? head_size : 2; a.rope_theta = rope_theta;
     a.rope_table = head_size > 0 ? rope_table_lookup(head_size, rope_theta) : nullptr;
+    a.early = g_tune[TUNE_QKV].early;
     return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
 }
 
@@ -543,6 +560,7 @@ int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const
     if (rc) return rc;
     fill_mat(a.m[0], gate); fill_mat(a.m[1], up);
     a.out[0] = out; a.x = x; a.rms_w = rms_w; a.dbg = g_dbg;
+    a.early = g_tune[TUNE_FFN].early;
     return launch_gemv_ffn(a, g_tune[TUNE_FFN].cols, g_tune[TUNE_FFN].waves);
 }
 
@@ -557,6 +575,7 @@ extern "C" {
 
 void q4_set_ablate(int mode) { g_ablate = mode; }
 void q4_set_ksplit(int on) { g_ksplit = on; }
+void q4_set_gemv_early(int kind, int slots) { if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots; }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 
 void q4_set_gemv_tune(int kind, int cols, int waves) {
@@ -597,6 +616,7 @@ int q4_matmul_q4(q4_half* xout, const q4_half* x, const QWeight* w, int inpSize,
     fill_mat(a.m[0], w);
     a.out[0] = xout; a.x = x; a.accum = accum; a.loff = loff; a.pPos = pPos;
     const GemvTune& t = g_tune[a.nslots <= 2 ? TUNE_PLAIN_SMALL : TUNE_PLAIN_BIG];
+    a.early = t.early;
     return launch_gemv_plain(a, t.cols, t.waves);
 }
 
@@ -609,6 +629,7 @@ int q4_qkv_matvec(q4_half* q, q4_half* key_cache, q4_half* value_cache, const q4
     fill_mat(a.m[0], qw); fill_mat(a.m[1], kw); fill_mat(a.m[2], vw);
     a.out[0] = q; a.out[1] = key_cache; a.out[2] = value_cache;
     a.x = x; a.pPos = pPos; a.loff = loff; a.rope = 0; a.head_size = 2;
+    a.early = g_tune[TUNE_QKV].early;
     return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
 }
 
@@ -713,3 +734,20 @@ int q4_argmax(const q4_half* x, int size, int* result, volatile int* pPos, int* 
 }
 
 }  // extern "C"
+
+// Warm the L2s with the first `blocks` consumer blocks' share of up to two QWeights (cols_per_block columns each).
+extern "C" int q4_touch_qweights(const QWeight* a, const QWeight* b, int K, int cols_per_block, int blocks) {
+    using namespace q4;
+    TouchArgs t{};
+    const int G = K / 128, pzh = (G + 7) / 8;
+    const QWeight* ws[2] = {a, b};
+    for (int i = 0; i < 2; i++) {
+        if (!ws[i]) continue;
+        t.p[t.n] = (const char*)ws[i]->weight; t.bytes[t.n++] = (unsigned)cols_per_block * (K / 2);
+        t.p[t.n] = (const char*)ws[i]->scales; t.bytes[t.n++] = (unsigned)cols_per_block * G * 2;
+        t.p[t.n] = (const char*)ws[i]->zeros;  t.bytes[t.n++] = (unsigned)cols_per_block * pzh * 4;
+    }
+    Q4_LAUNCH(touch_lines_kernel, dim3(blocks), dim3(256), 0, t, (unsigned*)nullptr);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}

@@ -341,6 +341,12 @@ TransformerWeights* q4_transformer_weights(Transformer* t) { return &t->weights;
 // run_llama_network, llama2_q4.cu:286-340
 #define Q4_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
+// measurement knob (tools/breakdown.py): leave out a class of launches to read its marginal cost inside the token
+// graph. Results are garbage with any bit set; never set by the product path.
+static int g_skip = 0;
+void q4_set_skip_mask(int mask) { g_skip = mask; q4_reset_graphs(); }
+#define Q4_UNLESS(bit, call) do { if (!(g_skip & (bit))) Q4_TRY(call); } while (0)
+
 int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin) {
     q4_half* x = s->x;
     const int dim = p->dim;
@@ -349,15 +355,15 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
     const int kv_mul = p->n_heads / p->n_kv_heads;
 
-    Q4_TRY(q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));       // :294
+    Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
         const int loff = l * p->seq_len * kv_dim;                                                      // :303
         if (g_fusion && dim == kv_dim) {
             // rmsnorm (:300) + qkv (:307) + RoPE (:317) in one launch
-            Q4_TRY(launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
-                                    dim, kv_dim, loff, pPos, head_size, p->rope_theta));
+            Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
+                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta));
         } else {
             Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_att_weight, dim));                                      // :300
             if (dim == kv_dim) {
@@ -369,20 +375,20 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache, p->n_heads, p->n_kv_heads, head_size, pPos, loff, p->rope_theta));   // :317
         }
-        Q4_TRY(launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
-                                seq_len_bin, pPos, (float*)s->att,
-                                (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half)));   // :320
-        Q4_TRY(q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                         // :323
+        Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
+                                      seq_len_bin, pPos, (float*)s->att,
+                                      (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half)));   // :320
+        Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
         if (g_fusion) {
-            Q4_TRY(launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
+            Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
         } else {
             Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_ffn_weight, dim));                                      // :326
             Q4_TRY(q4_ffn_matvec_silu(s->hb, s->xb, &L->wq_gate, &L->wq_up, dim, hidden_dim));         // :329
         }
-        Q4_TRY(q4_matmul_q4(s->x, s->hb, &L->wq_down, hidden_dim, dim, 1, -1, nullptr));               // :332
+        Q4_UNLESS(16, q4_matmul_q4(s->x, s->hb, &L->wq_down, hidden_dim, dim, 1, -1, nullptr));        // :332
     }
-    Q4_TRY(q4_rmsnorm(x, x, w->rms_final_weight, dim));                                                // :336
-    Q4_TRY(q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));         // :339
+    Q4_UNLESS(32, q4_rmsnorm(x, x, w->rms_final_weight, dim));                                         // :336
+    Q4_UNLESS(32, q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));  // :339
     return Q4_OK;
 }
 
@@ -444,7 +450,15 @@ int q4_sample(Sampler* sampler, RunState* s, int gen_token) { return sample_impl
 // run_transformer, llama2_q4.cu:346-395
 int q4_run_transformer(int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
                        Sampler* pSampler) {
-    const int seq_len = s->shared_data->pos + 1;                                   // :354
+    return q4_run_transformer_at(s->shared_data->pos, gen_token, p, s, w, copyLogits, pSampler);   // :354
+}
+
+// The same step with the position supplied by the caller instead of read back from SharedData::pos: the device keeps
+// its own position (`s->pos`) and reads its input token from the ring, so step pos+1 can be queued while step pos is
+// still running (generate() below); only the graph bin depends on the host's idea of the position.
+int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
+                          Sampler* pSampler) {
+    const int seq_len = pos + 1;                                                   // :354
     const bool greedy = sampler_is_greedy(pSampler, gen_token);
     int graphIndex;
     int seq_len_bin = 128;
@@ -489,6 +503,21 @@ int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_toke
     return Q4_OK;
 }
 int q4_shared_pos(const RunState* s) { return s->shared_data->pos; }
+// Wait until the device has published position >= pos (argmax_kernel / sample_scan_kernel write the token, fence, then
+// SharedData::pos -- "unblocks the CPU", gpu_kernels.h:490). Spins on the pinned word; falls back to the stream state
+// so that a failed launch cannot hang the host.
+int q4_wait_pos(const RunState* s, int pos) {
+    volatile int* p = &s->shared_data->pos;
+    for (unsigned spins = 1;; spins++) {
+        if (*p >= pos) return Q4_OK;
+        if ((spins & 0x3fff) == 0) {
+            hipError_t e = hipStreamQuery(g_stream);
+            if (e == hipSuccess) return *p >= pos ? Q4_OK : Q4_ERR_ARG;           // stream drained: pos is final
+            if (e != hipErrorNotReady) Q4_HIP(e);
+        }
+        __builtin_ia32_pause();
+    }
+}
 int q4_shared_token(const RunState* s, int index) { return s->shared_data->tokens[index]; }
 
 int q4_get_logits(const Transformer* t, q4_half* host_out) {
@@ -529,8 +558,10 @@ double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_token
     int pos = 0;
     if (q4_reset_sequence(&t->state, prompt_tokens, num_prompt_tokens)) return -1.0;
     while (pos < steps) {
-        if (hipStreamSynchronize(g_stream) != hipSuccess) return -1.0;             // :468
-        if (q4_run_transformer(pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+        // the reference synchronises and then launches step `pos` (:468-470); here the launch goes out first, queued
+        // behind step pos-1, and the host then waits for step pos-1's token -- same device order, no idle gap per token
+        if (q4_run_transformer_at(pos, pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+        if (q4_wait_pos(&t->state, pos)) return -1.0;                              // :468
         if (pos > 0) {
             int next = t->state.shared_data->tokens[pos];                          // :473
             if (next >= t->config.vocab_size) next = 0;                            // :474

@@ -118,9 +118,10 @@ __global__ void sample_scan_kernel(const uint16_t* probs, const int* indices, in
         run = round_h(run + h2f(probs[t]));              // fp16 accumulator
         if (run >= threshold) { min_index = t; break; }
     }
-    int token_pos = *pPos;
+    int token_pos = *pPosGpu;                            // == *pPos (:579-580) without the PCIe read
     token_pos++;
     result[token_pos] = indices[min_index];              // :578
+    __threadfence_system();                              // the host may be spinning on *pPos (q4_wait_pos)
     *pPos = token_pos;
     *pPosGpu = token_pos;
 }

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Early-bird sweep: waves in the first E slots of each SIMD issue their weight loads before the x staging completes."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llama_cu_awq_amd import api, synth   # noqa: E402
+
+model = sys.argv[1] if len(sys.argv) > 1 else "7b"
+path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
+if not os.path.exists(path):
+    synth.write_model(path, model)
+L = api.lib()
+L.q4_set_gemv_early.argtypes = [C.c_int, C.c_int]
+api.check(L.q4_set_device(0))
+s = C.c_void_p()
+api.check(L.q4_stream_create(C.byref(s)))
+L.q4_set_stream(s)
+tr = api.Transformer(path)
+big = tr.config.dim > 4096
+for kid, kind, name in ((0, 3, "gate/up"), (3, 2, "qkv"), (2, 1, "down"), (1, 1 if big else 0, "dim->hidden plain"), (4, 1 if big else 0, "o-proj")):
+    for e in (0, 1, 2, 3, 4, 5, 6, 8, 12, 16):
+        L.q4_set_gemv_early(kind, e)
+        g = min(tr.bench_kernel_graph(kid, 32, 20) for _ in range(3))
+        print("%-18s early %d : %.2f us" % (name, e, g), flush=True)
+    L.q4_set_gemv_early(kind, 0)
+tr.close()

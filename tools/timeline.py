@@ -26,6 +26,14 @@ for i, n in enumerate(names):
     if i == 6: continue
     c = r[:, i]
     print("%-28s min %7d  p10 %7d  median %7d  p90 %7d  max %7d" % (n, c.min(), np.percentile(c, 10), np.median(c), np.percentile(c, 90), c.max()))
+rt = (t[:, 6] - t[:, 6].min()) * 0.01           # us since the first wave's entry (constant 100 MHz clock)
+life = (t[:, 7] - t[:, 0]) / 2.1e3               # us, shader clock ~2.1 GHz
+print("entry time, us after the first wave: p10 %.2f median %.2f p90 %.2f max %.2f" % tuple(np.percentile(rt, [10, 50, 90, 100])))
+print("end time,   us after the first wave: p10 %.2f median %.2f p90 %.2f max %.2f" % tuple(np.percentile(rt + life, [10, 50, 90, 100])))
+h, _ = np.histogram(rt, bins=np.arange(0, rt.max() + 0.5, 0.5))
+print("waves entering per 0.5 us:", h.tolist())
+h, _ = np.histogram(rt + life, bins=np.arange(0, (rt + life).max() + 0.5, 0.5))
+print("waves ending per 0.5 us:  ", h.tolist())
 d = t[:, 7] - t[:, 0]
 print("wave lifetime: median %d max %d cycles" % (np.median(d), d.max()))
 for a, b in [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 7)]:
