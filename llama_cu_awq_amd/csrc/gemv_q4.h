@@ -220,24 +220,16 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     // x loads, or park this wave in issue back-pressure). The first `a.early` waves the dispatcher placed on the CU (HW_ID rank): once their own x has arrived (by then every other wave's x loads
     // are queued too) they put their weight loads in flight and only then finish the staging, so HBM streams during
     // the ~1.9 us x chain of the launch. Kept to ~64 KB per CU: those loads are accepted without back-pressure.
-    const bool early = ABL != 4 && ABL != 5 && PRE < SLOTS && a.early > 0 && early_rank() < a.early;
+    const bool early = ABL != 4 && ABL != 5 && PRE < SLOTS && a.early > 0 && early_rank() < (a.early & 255);
     // (single load site in program order, the staging tail before OR after it: after a two-path join with loads on
     // both sides hipcc's waitcnt pass falls back to vmcnt(0) and the progressive per-slot waits are lost)
-    float psum[TS];
-    if (NORM) {
-#pragma unroll
-        for (int i = 0; i < TS; i++) psum[i] = sumsq8(xraw[i], 0.f);
-        asm volatile("" ::"v"(psum[TS - 1]));           // x has arrived
-    } else {
-        asm volatile("" ::"v"(xraw[TS - 1]));
-    }
     auto stage_tail = [&]() {
         float ss = 1.f;
         if (NORM) {
 #pragma unroll
             for (int i = 0; i < TS; i++) {
                 const unsigned u = tid + i * blockDim.x;
-                if (u < NUNITS) part[u] = u < nchunks ? psum[i] : 0.f;
+                if (u < NUNITS) part[u] = u < nchunks ? sumsq8(xraw[i], 0.f) : 0.f;
             }
             __syncthreads();
             if (ABL == 3) ts[2] = __builtin_readcyclecounter();
@@ -265,6 +257,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         __syncthreads();
         if (ABL == 3) ts[3] = __builtin_readcyclecounter();
     };
+    if (early) {    // give the waves that entered last time to queue their x loads (bits 8+ of a.early, 128-cycle steps)
+        for (int i = a.early >> 8; i > 0; i--) __builtin_amdgcn_s_sleep(2);
+    }
     if (ABL != 4 && !early) stage_tail();      // (ABL 4: no staging at all, garbage x -- the kernel without the x chain)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -402,14 +397,30 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     }
 }
 
+static inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 // host-side dispatch -------------------------------------------------------------------------------
 extern int g_ablate;
 extern int g_ksplit;    // 1: split K over two waves for the plain GEMV (default), 0: one wave per column group
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1>
-static int launch_one(const GemvArgs& a, int waves) {
+static int launch_one(const GemvArgs& a0, int waves) {
     if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS / 64;
     const int cols_per_block = COLS * (waves / KS);
-    dim3 grid(divUp(a.N, cols_per_block), MODE == MODE_QKV ? 3 : 1);
+    dim3 grid(divUp(a0.N, cols_per_block), MODE == MODE_QKV ? 3 : 1);
+    GemvArgs a = a0;
+    if (a.early > 0 && a.early < 256) {
+        // early birds hold back until the launch's x loads are queued: that takes longer the more waves share a CU
+        // (measured, tools/sweep_early.py: <= 12 waves per CU none, 15 -> 4 x 128 cycles, >= 21 -> 8 x 128)
+        const int waves_per_cu = (int)((size_t)grid.x * grid.y * waves / (size_t)cu_count());
+        a.early |= (waves_per_cu <= 12 ? 0 : waves_per_cu <= 16 ? 4 : 8) << 8;
+    }
     constexpr int TS = SLOTS * KS;
     const size_t smem = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
     Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>), grid, dim3(waves * 64), smem, a);

@@ -16,9 +16,10 @@ enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUN
 int g_ablate = 0;
 int g_ksplit = 1;
 unsigned long long* g_dbg = nullptr;
-// early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain; the
-// gate/up launch with 21 waves per CU gets slower with any early bird)
-static GemvTune g_tune[TUNE_COUNT] = {{4, 4, 4}, {4, 4, 4}, {4, 4, 4}, {2, 4, 0}};
+// early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain). The
+// hold-back before the early loads (bits 8+, 128-cycle steps) is chosen per launch in launch_one(): with 21 waves per CU
+// (gate/up) the x loads take ~0.5 us to queue and early weight requests in front of them make those blocks straggle
+static GemvTune g_tune[TUNE_COUNT] = {{4, 4, 4}, {4, 4, 4}, {4, 4, 4}, {2, 4, 4}};
 
 // ------------------------------------------------------------------------------------------------
 // rmsnorm_kernel (gpu_kernels.h:72-105). One block; 16-byte loads; the canonical chunk-partial reduction

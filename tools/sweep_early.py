@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Early-bird sweep: waves in the first E slots of each SIMD issue their weight loads before the x staging completes."""
+"""Early-bird sweep: the first E waves placed on each CU issue their weight loads D x 128 cycles after their x loads,
+before the x staging completes (in-graph us per launch).  tools/sweep_early.py [7b|13b]"""
 import ctypes as C
 import os
 import sys
@@ -19,10 +20,10 @@ api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 tr = api.Transformer(path)
 big = tr.config.dim > 4096
-for kid, kind, name in ((0, 3, "gate/up"), (3, 2, "qkv"), (2, 1, "down"), (1, 1 if big else 0, "dim->hidden plain"), (4, 1 if big else 0, "o-proj")):
-    for e in (0, 1, 2, 3, 4, 5, 6, 8, 12, 16):
-        L.q4_set_gemv_early(kind, e)
+for kid, kind, name in ((0, 3, "gate/up"), (3, 2, "qkv"), (2, 1, "down"), (4, 1 if big else 0, "o-proj")):
+    for e, d in ((0, 0), (4, 0), (4, 2), (4, 4), (4, 6), (4, 8), (4, 10), (4, 12), (4, 16), (8, 0), (8, 8), (8, 12)):
+        L.q4_set_gemv_early(kind, e | (d << 8))
         g = min(tr.bench_kernel_graph(kid, 32, 20) for _ in range(3))
-        print("%-18s early %d : %.2f us" % (name, e, g), flush=True)
+        print("%-8s early %d delay %2d : %.2f us" % (name, e, d, g), flush=True)
     L.q4_set_gemv_early(kind, 0)
 tr.close()
