@@ -314,6 +314,13 @@ double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, const Transf
  * microseconds per launch. ids as above, plus 6: attention, 7: rmsnorm, 8: argmax, 9: embedding copy. */
 double q4_bench_kernel_graph(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
                              int reps);
+/* Average duration of one launch class INSIDE the eager decode network (inputs produced by the previous kernel,
+ * caches as the token loop leaves them): runs `tokens` greedy decode steps from the current position with dispatch
+ * timestamps on the launches in time_mask | report_mask, statistics over report_mask (1 qkv, 2 attention, 4 o-proj, 8 gate/up, 16 down,
+ * 32 final norm + classifier, 64 embedding); microseconds, <0 on error. This is the duration bench.py's roofline
+ * uses and the one `rocprofv3 --kernel-trace` reports for `bench.py --no-graphs`. */
+double q4_bench_in_network(int time_mask, int report_mask, const Config* p, RunState* s, const TransformerWeights* w,
+                           int tokens, double* min_us, double* max_us, int* launches);
 int q4_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes);
 
 #ifdef __cplusplus

@@ -59,7 +59,7 @@ SYMBOLS = [
     "q4_generate_ids", "q4_chat", "q4_softmax_f32", "compute_perplexity", "q4_get_dataset_perplexity",
     "q4_parse_dataset_and_compute_perplexity", "q4_perplexity_ids", "q4_tokenizer_new", "q4_tokenizer_delete",
     "q4_tokenizer_encode", "q4_tokenizer_decode", "q4_tokenizer_max_token_length", "q4_main", "q4_parse_args",
-    "q4_bench_kernel", "q4_bench_kernel_graph", "q4_device_info",
+    "q4_bench_kernel", "q4_bench_kernel_graph", "q4_bench_in_network", "q4_device_info",
 ]
 
 _lib = None
@@ -157,6 +157,9 @@ def lib():
     L.q4_bench_kernel.restype = C.c_double
     L.q4_bench_kernel_graph.argtypes = [i, C.POINTER(Config), C.POINTER(RunState), C.POINTER(TransformerWeights), i, i]
     L.q4_bench_kernel_graph.restype = C.c_double
+    L.q4_bench_in_network.argtypes = [i, i, C.POINTER(Config), C.POINTER(RunState), C.POINTER(TransformerWeights), i,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i)]
+    L.q4_bench_in_network.restype = C.c_double
     L.q4_device_info.argtypes = [C.c_char_p, i, C.POINTER(i), C.POINTER(C.c_size_t)]
     L.q4_set_gemv_tune.argtypes = [i, i, i]
     L.q4_set_gemv_tune.restype = None
@@ -358,6 +361,17 @@ class Transformer:
             raise Q4Error("bench_kernel failed: " + lib().q4_last_error().decode())
         return avg, mn.value, mx.value
 
+
+    def bench_in_network(self, report_mask, tokens=8, time_mask=127):
+        """(avg, min, max us, launches) of one launch class inside the eager decode network, from the current position."""
+        mn = C.c_double()
+        mx = C.c_double()
+        n = C.c_int()
+        avg = lib().q4_bench_in_network(time_mask, report_mask, C.byref(self.config), self.state, self.weights, tokens, C.byref(mn),
+                                        C.byref(mx), C.byref(n))
+        if avg < 0:
+            raise Q4Error("bench_in_network failed: " + lib().q4_last_error().decode())
+        return avg, mn.value, mx.value, n.value
 
     def bench_kernel_graph(self, kernel_id, iters=32, reps=20):
         us = lib().q4_bench_kernel_graph(kernel_id, C.byref(self.config), self.state, self.weights, iters, reps)

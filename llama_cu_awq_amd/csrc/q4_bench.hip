@@ -5,9 +5,6 @@
 #include "q4_internal.h"
 using namespace q4;
 
-extern "C" int q4_touch_qweights(const QWeight* a, const QWeight* b, int K, int cols_per_block, int blocks);
-static int g_touch_blocks = 600;
-extern "C" void q4_set_touch_blocks(int n) { g_touch_blocks = n; }
 static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, const TransformerWeights* w) {
     const int dim = p->dim, hidden = p->hidden_dim;
     const int head_size = dim / p->n_heads;
@@ -28,12 +25,6 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
         case 7: return q4_rmsnorm(s->xb, s->x, w->rms_final_weight, dim);
         case 8: return q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 0);
         case 9: return q4_copy_embedding(s->x, w->token_embedding_table, dim, s->shared_data->tokens, s->pos);
-        case 10: return q4_touch_qweights(&L->wq_o, nullptr, dim, 16, dim / 16);
-        case 11: { int rc = q4_touch_qweights(&L->wq_o, nullptr, dim, 16, dim / 16);
-                   return rc ? rc : q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr); }
-        case 12: return q4_touch_qweights(&L->wq_gate, &L->wq_up, dim, 8, g_touch_blocks);
-        case 13: { int rc = q4_touch_qweights(&L->wq_gate, &L->wq_up, dim, 8, g_touch_blocks);
-                   return rc ? rc : launch_ffn_fused(s->hb, s->x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden); }
     }
     return Q4_ERR_ARG;
 }

@@ -476,19 +476,6 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
     }
 }
 
-// L2 warm-up of a QWeight slice: block b touches one dword per 128-B line of the bytes the consumer GEMV's block b
-// will stream (blocks b of consecutive dispatches land on XCD b % 8 -- a speed-only hint, never a dependency).
-struct TouchArgs { const char* p[6]; unsigned bytes[6]; int n; };
-__global__ void __launch_bounds__(256) touch_lines_kernel(TouchArgs a, unsigned* sink) {
-    unsigned acc = 0;
-    for (int r = 0; r < a.n; r++) {
-        const char* base = a.p[r] + (size_t)blockIdx.x * a.bytes[r];
-        for (unsigned off = threadIdx.x * 128u; off < a.bytes[r]; off += 256u * 128u)
-            acc ^= *reinterpret_cast<const unsigned*>(base + off);
-    }
-    if (acc == 0x9e3779b9u && sink) *sink = acc;      // keeps the loads alive, practically never taken
-}
-
 // (cos, sin) of every (position, pair) with the reference's own formula, so that table lookups in the fused QKV
 // epilogue are bit-identical to RoPERotation_kernel's on-the-fly powf/cosf/sinf (~300 VALU per wave saved)
 __global__ void rope_table_kernel(float2* table, int seq_len, int head_size, float rope_theta) {
@@ -736,19 +723,3 @@ int q4_argmax(const q4_half* x, int size, int* result, volatile int* pPos, int* 
 
 }  // extern "C"
 
-// Warm the L2s with the first `blocks` consumer blocks' share of up to two QWeights (cols_per_block columns each).
-extern "C" int q4_touch_qweights(const QWeight* a, const QWeight* b, int K, int cols_per_block, int blocks) {
-    using namespace q4;
-    TouchArgs t{};
-    const int G = K / 128, pzh = (G + 7) / 8;
-    const QWeight* ws[2] = {a, b};
-    for (int i = 0; i < 2; i++) {
-        if (!ws[i]) continue;
-        t.p[t.n] = (const char*)ws[i]->weight; t.bytes[t.n++] = (unsigned)cols_per_block * (K / 2);
-        t.p[t.n] = (const char*)ws[i]->scales; t.bytes[t.n++] = (unsigned)cols_per_block * G * 2;
-        t.p[t.n] = (const char*)ws[i]->zeros;  t.bytes[t.n++] = (unsigned)cols_per_block * pzh * 4;
-    }
-    Q4_LAUNCH(touch_lines_kernel, dim3(blocks), dim3(256), 0, t, (unsigned*)nullptr);
-    Q4_LAUNCH_CHECK();
-    return Q4_OK;
-}

@@ -345,7 +345,22 @@ TransformerWeights* q4_transformer_weights(Transformer* t) { return &t->weights;
 // graph. Results are garbage with any bit set; never set by the product path.
 static int g_skip = 0;
 void q4_set_skip_mask(int mask) { g_skip = mask; q4_reset_graphs(); }
-#define Q4_UNLESS(bit, call) do { if (!(g_skip & (bit))) Q4_TRY(call); } while (0)
+// in-network timing (q4_bench_in_network): launches of the class whose bit is in g_time_mask carry dispatch timestamps
+static int g_time_mask = 0;
+static std::vector<hipEvent_t>* g_time_events = nullptr;
+static std::vector<int>* g_time_bits = nullptr;
+static inline void arm_timing(int bit) {
+    g_ev_start = g_ev_stop = nullptr;
+    if (!(g_time_mask & bit) || !g_time_events) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_time_events->push_back(a);
+    g_time_events->push_back(b);
+    if (g_time_bits) g_time_bits->push_back(bit);
+    g_ev_start = a;
+    g_ev_stop = b;
+}
+#define Q4_UNLESS(bit, call) do { if (!(g_skip & (bit))) { if (g_time_mask) arm_timing(bit); int rc__ = (call); g_ev_start = g_ev_stop = nullptr; if (rc__) return rc__; } } while (0)
 
 int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin) {
     q4_half* x = s->x;
@@ -390,6 +405,51 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     Q4_UNLESS(32, q4_rmsnorm(x, x, w->rms_final_weight, dim));                                         // :336
     Q4_UNLESS(32, q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));  // :339
     return Q4_OK;
+}
+
+// Average duration of one launch class INSIDE the eager decode network (x produced by the previous kernel, caches
+// in the state the real token loop leaves them): `tokens` decode steps from the current position with dispatch
+// timestamps on the launches of time_mask | report_mask (1 qkv, 2 attention, 4 o-proj, 8 gate/up, 16 down, 32 final
+// norm + classifier, 64 embedding); the statistics cover report_mask. The launches are the product's own, only
+// hipExtLaunchKernelGGL carries the events.
+double q4_bench_in_network(int time_mask, int report_mask, const Config* p, RunState* s, const TransformerWeights* w,
+                           int tokens, double* min_us, double* max_us, int* launches) {
+    if (!p || !s || !w || tokens < 1 || !g_stream) return -1.0;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> bits;
+    int rc = 0;
+    const int pos0 = s->shared_data->pos;
+    for (int t = 0; t < tokens && !rc; t++) {
+        const int pos = pos0 + t;
+        if (pos + 1 >= p->seq_len) break;
+        g_time_events = &ev;
+        g_time_bits = &bits;
+        g_time_mask = time_mask | report_mask;
+        rc = q4_run_llama_network(s->pos, p, s, w, pos + 1);
+        g_time_mask = 0;
+        g_time_events = nullptr;
+        g_time_bits = nullptr;
+        if (!rc) rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 1);
+    }
+    if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) rc = Q4_ERR_HIP;
+    double total = 0, mn = 1e30, mx = 0;
+    int n = 0;
+    for (size_t i = 0; i < bits.size() && !rc; i++) {
+        if (!(bits[i] & report_mask)) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { rc = Q4_ERR_HIP; break; }
+        const double us = ms * 1000.0;
+        total += us;
+        n++;
+        if (us < mn) mn = us;
+        if (us > mx) mx = us;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    if (rc || n == 0) return -1.0;
+    if (min_us) *min_us = mn;
+    if (max_us) *max_us = mx;
+    if (launches) *launches = n;
+    return total / n;
 }
 
 // ---------------------------------------------------------------------------------------------------
