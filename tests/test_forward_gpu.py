@@ -114,3 +114,41 @@ def test_perplexity_path(q4, orc, models):
     assert abs(ppl - rppl) <= 5e-3 * rppl, (ppl, rppl)      # perplexity within 0.5 %
     t.close()
     m.close()
+
+
+def test_pipelined_generate_equals_stepwise_run_transformer(q4, models):
+    """generate() queues step pos before it has seen step pos-1's token (q4_run_transformer_at + q4_wait_pos); the
+    token ring must equal the reference order: synchronise, run_transformer, read (llama2_q4.cu:468-474)."""
+    prompt = [1, 400, 22, 7, 513]
+    steps = 40
+    t = q4.Transformer(models["small"])
+    gtoks, tps, timed, secs = t.generate_ids(prompt, steps)
+    t.reset(prompt)
+    ring = list(prompt)
+    for pos in range(steps):
+        q4.synchronize()
+        t.run_transformer(pos >= len(prompt) - 1)
+        q4.synchronize()
+        if pos + 1 >= len(prompt):
+            ring.append(int(t.token(pos + 1)))
+    n = min(len(gtoks), len(ring))
+    assert n >= steps - 1
+    stop = next((i for i in range(1, n) if ring[i] == 2), n)       # generate() stops at EOS
+    assert list(gtoks[:stop]) == ring[:stop]
+    t.close()
+
+
+def test_bench_in_network_times_the_products_own_launches(q4, models):
+    t = q4.Transformer(models["small"])
+    prompt = [1, 400, 22, 7]
+    t.reset(prompt)
+    for pos in range(6):
+        t.run_transformer(pos >= len(prompt) - 1)
+        q4.synchronize()
+    before = int(t.pos())
+    avg, mn, mx, n = t.bench_in_network(8, tokens=3)
+    assert n == 3 * t.config.n_layers and 0 < mn <= avg <= mx < 1e4
+    assert int(t.pos()) == before + 3                       # three real decode steps were taken
+    avg_all, _, _, n_all = t.bench_in_network(1 | 2 | 4 | 8 | 16, tokens=1)
+    assert n_all == 5 * t.config.n_layers and avg_all > 0
+    t.close()

@@ -119,3 +119,33 @@ def test_linearity_full_size(q4, rng):
     q4.synchronize()
     a, b = o1.get(np.float16, N).astype(np.float32), o2.get(np.float16, N).astype(np.float32)
     assert np.array_equal(a * 2, b)
+
+
+@pytest.mark.parametrize("K,N,kind", [(4096, 4096, 0), (11008, 4096, 1), (13824, 5120, 1), (4096, 11008, 3), (5120, 13824, 3)])
+def test_early_bird_issue_order_is_bit_neutral(q4, rng, K, N, kind):
+    """The early-bird issue order (first block per CU sends its weight loads before the staging completes) only moves
+    loads in time: outputs must be bit-identical with it switched off, with the default, and with odd settings."""
+    import ctypes as C
+    L = q4.lib()
+    L.q4_set_gemv_early.argtypes = [C.c_int, C.c_int]
+    L.q4_set_gemv_early.restype = None
+    x = rng.standard_normal(K).astype(np.float16)
+    dx, dout = q4.DevBuf(x), q4.DevBuf(nbytes=N * 2)
+    if kind == 3:
+        g, u = synth.random_qweight(rng, K, N), synth.random_qweight(rng, K, N)
+        dg, du = q4.DevQWeight(*g), q4.DevQWeight(*u)
+        run = lambda: q4.ffn_matvec_silu(dout, dx, dg, du, K, N)
+    else:
+        dw = q4.DevQWeight(*synth.random_qweight(rng, K, N))
+        run = lambda: q4.matmul_q4(dout, dx, dw, K, N)
+    outs = []
+    try:
+        for early in (0, 4, 4 | (8 << 8), 7, 64):
+            L.q4_set_gemv_early(kind, early)
+            run()
+            q4.synchronize()
+            outs.append(dout.get(np.float16, N).view(np.uint16).copy())
+    finally:
+        L.q4_set_gemv_early(kind, 4)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
