@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--model-dir", default=os.environ.get("Q4_MODEL_DIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--f64-steps", type=int, default=10, help="positions of the unrounded double forward used as parity yardstick")
     ap.add_argument("--force-dist", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
     args = ap.parse_args()
@@ -202,8 +203,10 @@ def main():
         worst = 0.0
         agree = 0
         tr.reset(PROMPT_IDS)
+        refs = []
         for pos in range(min(args.cpu_steps, ntok)):
             ref = m.forward(ctoks[pos], pos)
+            refs.append(ref)
             n_done += 1
             if pos >= len(PROMPT_IDS) - 1:
                 ctoks.append(int(np.argmax(ref.astype(np.float32))))
@@ -222,6 +225,26 @@ def main():
         agree = int(sum(int(tr.token(i)) == ctoks[i] for i in range(len(PROMPT_IDS), min(len(ctoks), n_done + 1))))
         parity = {"positions": n_done, "last_logits_max_rel_err": round(worst, 5),
                   "greedy_tokens_agree": "%d/%d" % (agree, max(0, min(len(ctoks), n_done + 1) - len(PROMPT_IDS)))}
+        # yardstick: the same network in double without intermediate rounding (oracle orc_forward_f64) for the first
+        # positions -- how far each of the two fp16 evaluations (GPU, reference-order restatement) is from it
+        n64 = min(n_done, args.f64_steps)
+        if n64 > 0:
+            t64 = time.perf_counter()
+            for pos in range(n64):
+                exact = m.forward_f64(ctoks[pos], pos, cap=n64)
+            tr.reset(PROMPT_IDS)
+            for pos in range(n64):
+                tr.run_transformer(pos >= len(PROMPT_IDS) - 1)
+                api.synchronize()
+            g64 = tr.logits().astype(np.float64)
+            r64 = refs[n64 - 1].astype(np.float64)
+            den = np.maximum(1.0, np.abs(exact))
+            parity["vs_unrounded_f64"] = {"position": n64 - 1, "gpu_max_rel_err": round(float(np.max(np.abs(g64 - exact) / den)), 5),
+                                          "cpu_restatement_max_rel_err": round(float(np.max(np.abs(r64 - exact) / den)), 5),
+                                          "gpu_rms_err": round(float(np.sqrt(np.mean((g64 - exact) ** 2))), 5),
+                                          "cpu_restatement_rms_err": round(float(np.sqrt(np.mean((r64 - exact) ** 2))), 5),
+                                          "argmax_equal": bool(int(np.argmax(g64)) == int(np.argmax(exact))),
+                                          "seconds": round(time.perf_counter() - t64, 1)}
         cpu = {"value": round(n_done / cpu_secs, 4), "unit": "tokens/s", "cores": nthreads, "kind": "port",
                "sample": "%d decode steps (positions 0..%d) of the same %s checkpoint, CPU restatement of run_llama_network "
                          "(oracle/q4_oracle.c, OpenMP); the reference has no CPU path" % (n_done, n_done - 1, args.model)}

@@ -99,6 +99,8 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.orc_forward.restype = None
     L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_forward_f64.restype = C.c_int
+    L.orc_forward_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.orc_generate_greedy.restype = C.c_int
     L.orc_generate_greedy.argtypes = [C.c_void_p, i32p, C.c_int, C.c_int, i32p, C.c_void_p]
     L.orc_num_threads.restype = C.c_int
@@ -198,6 +200,15 @@ class Model:
     def forward(self, token, pos):
         self.L.orc_forward(self.h, token, pos)
         return self.logits()
+
+    def forward_f64(self, token, pos, cap=32):
+        """The same network function evaluated in double without any intermediate rounding (the yardstick for two
+        valid fp16 evaluations that drift apart). Positions must be fed in order from 0; `cap` positions are kept."""
+        out = np.empty(self.cfg.vocab_size, dtype=np.float64)
+        rc = self.L.orc_forward_f64(self.h, int(token), int(pos), int(cap), out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc:
+            raise RuntimeError("orc_forward_f64 failed: %d" % rc)
+        return out
 
     def logits(self):
         return np.ctypeslib.as_array(self.L.orc_logits(self.h), shape=(self.cfg.vocab_size,)).view(np.float16).copy()

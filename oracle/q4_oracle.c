@@ -58,6 +58,9 @@ typedef struct {
     f16 *x, *xb, *hb, *q, *att, *logits, *key_cache, *value_cache;
     int pos;
     int *tokens;
+    /* unrounded evaluation (orc_forward_f64): double KV cache for the first f64_cap positions */
+    double *k64, *v64;
+    int f64_cap;
 } OrcModel;
 
 /* ---- fp16 <-> fp32, exact IEEE binary16, round-to-nearest-even ------------- */
@@ -520,7 +523,8 @@ OrcModel *orc_load(const char *path) {
 void orc_free(OrcModel *m) {
     if (!m) return;
     free(m->x); free(m->xb); free(m->hb); free(m->q); free(m->att); free(m->logits);
-    free(m->key_cache); free(m->value_cache); free(m->tokens); free(m->layers); free(m->blob); free(m);
+    free(m->key_cache); free(m->value_cache); free(m->tokens); free(m->layers); free(m->blob);
+    free(m->k64); free(m->v64); free(m);
 }
 
 const OrcConfig *orc_config(const OrcModel *m) { return &m->cfg; }
@@ -556,6 +560,107 @@ void orc_forward(OrcModel *m, int token, int pos) {
     }
     orc_rmsnorm(x, x, m->rms_final, dim);                                     /* :336 (in place) */
     orc_matmul_f16(m->logits, x, m->wcls, p->dim, p->vocab_size, 1.0f);       /* :339 */
+}
+
+/* ---- the same network function without any intermediate rounding (double everywhere, weights and embeddings as
+ * stored): the yardstick both the reference-order restatement above and the GPU path are measured against where two
+ * valid fp16 evaluations drift apart (deep random-weight models). Not a restatement of reference code: it follows
+ * run_llama_network's dataflow (llama2_q4.cu:286-340) with exact arithmetic in place of each kernel. Positions must be
+ * fed in order 0,1,2..; `cap` positions of double KV cache are kept. logits_out: vocab doubles. Returns 0 on success. */
+static void matvec_q4_f64(double *out, const double *x, const OrcQWeight *w, int K, int N, int accum) {
+    int sh = divUp(K, 128), pwh = divUp(K, 32) * 4, pzh = divUp(sh, 8);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; n++) {
+        double sum = 0.0;
+        for (int g = 0; g < sh; g++) {
+            uint32_t z = (w->zeros[(size_t)n * pzh + g / 8] >> (4 * (g % 8))) & 0xF;
+            double sc = (double)h2f(w->scales[(size_t)n * sh + g]);
+            double part = 0.0;
+            int k1 = (g + 1) * 128 < K ? (g + 1) * 128 : K;
+            for (int k = g * 128; k < k1; k++) {
+                uint32_t q = (w->weight[(size_t)n * pwh + k / 8] >> (4 * (k % 8))) & 0xF;
+                part += ((double)q - (double)z) * x[k];
+            }
+            sum += part * sc;
+        }
+        out[n] = accum ? out[n] + sum : sum;
+    }
+}
+static void rmsnorm_f64(double *o, const double *x, const f16 *w, int n) {
+    double ss = 0.0;
+    for (int i = 0; i < n; i++) ss += x[i] * x[i];
+    ss = 1.0 / sqrt(ss / n + 1e-5);                                            /* gpu_kernels.h:98-99 */
+    for (int i = 0; i < n; i++) o[i] = x[i] * ss * (double)h2f(w[i]);
+}
+int orc_forward_f64(OrcModel *m, int token, int pos, int cap, double *logits_out) {
+    OrcConfig *p = &m->cfg;
+    int dim = p->dim, hidden = p->hidden_dim, hs = dim / p->n_heads;
+    int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads, kv_mul = p->n_heads / p->n_kv_heads;
+    if (cap < 1 || pos < 0 || pos >= cap) return -1;
+    if (m->f64_cap != cap) {
+        free(m->k64); free(m->v64);
+        m->k64 = (double *)calloc((size_t)p->n_layers * cap * kv_dim, sizeof(double));
+        m->v64 = (double *)calloc((size_t)p->n_layers * cap * kv_dim, sizeof(double));
+        m->f64_cap = cap;
+        if (!m->k64 || !m->v64) return -2;
+    }
+    double *x = (double *)malloc(sizeof(double) * dim), *xb = (double *)malloc(sizeof(double) * dim);
+    double *q = (double *)malloc(sizeof(double) * dim), *hb = (double *)malloc(sizeof(double) * hidden);
+    double *hb2 = (double *)malloc(sizeof(double) * hidden), *att = (double *)malloc(sizeof(double) * (pos + 1));
+    for (int i = 0; i < dim; i++) x[i] = (double)h2f(m->embed[(size_t)token * dim + i]);
+    for (int l = 0; l < p->n_layers; l++) {
+        OrcLayer *L = &m->layers[l];
+        double *kc = m->k64 + ((size_t)l * cap + pos) * kv_dim, *vc = m->v64 + ((size_t)l * cap + pos) * kv_dim;
+        rmsnorm_f64(xb, x, L->rms_att, dim);
+        matvec_q4_f64(q, xb, &L->q, dim, dim, 0);
+        matvec_q4_f64(kc, xb, &L->k, dim, kv_dim, 0);
+        matvec_q4_f64(vc, xb, &L->v, dim, kv_dim, 0);
+        for (int h = 0; h < p->n_heads; h++)                                   /* RoPE, gpu_kernels.h:332-355 */
+            for (int i = 0; i < hs / 2; i++) {
+                double freq = 1.0 / pow((double)p->rope_theta, (double)(2 * i) / (double)hs);
+                double c = cos(pos * freq), s = sin(pos * freq);
+                double a = q[h * hs + i], b = q[h * hs + i + hs / 2];
+                q[h * hs + i] = a * c - b * s;
+                q[h * hs + i + hs / 2] = a * s + b * c;
+                if (h < p->n_kv_heads) {
+                    a = kc[h * hs + i]; b = kc[h * hs + i + hs / 2];
+                    kc[h * hs + i] = a * c - b * s;
+                    kc[h * hs + i + hs / 2] = a * s + b * c;
+                }
+            }
+        for (int h = 0; h < p->n_heads; h++) {                                 /* MHA, llama2_q4.cu:267-284 */
+            const double *kb = m->k64 + (size_t)l * cap * kv_dim + (size_t)(h / kv_mul) * hs;
+            const double *vb = m->v64 + (size_t)l * cap * kv_dim + (size_t)(h / kv_mul) * hs;
+            double mx = -1e300, sum = 0.0;
+            for (int t = 0; t <= pos; t++) {
+                double sdot = 0.0;
+                for (int i = 0; i < hs; i++) sdot += q[h * hs + i] * kb[(size_t)t * kv_dim + i];
+                att[t] = sdot / sqrt((double)hs);
+                if (att[t] > mx) mx = att[t];
+            }
+            for (int t = 0; t <= pos; t++) { att[t] = exp(att[t] - mx); sum += att[t]; }
+            for (int i = 0; i < hs; i++) {
+                double o = 0.0;
+                for (int t = 0; t <= pos; t++) o += att[t] / sum * vb[(size_t)t * kv_dim + i];
+                xb[h * hs + i] = o;
+            }
+        }
+        matvec_q4_f64(x, xb, &L->o, dim, dim, 1);
+        rmsnorm_f64(xb, x, L->rms_ffn, dim);
+        matvec_q4_f64(hb, xb, &L->gate, dim, hidden, 0);
+        matvec_q4_f64(hb2, xb, &L->up, dim, hidden, 0);
+        for (int i = 0; i < hidden; i++) hb[i] = hb[i] / (1.0 + exp(-hb[i])) * hb2[i];   /* gpu_kernels.h:271-272 */
+        matvec_q4_f64(x, hb, &L->down, hidden, dim, 1);
+    }
+    rmsnorm_f64(xb, x, m->rms_final, dim);
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < p->vocab_size; v++) {
+        double sdot = 0.0;
+        for (int i = 0; i < dim; i++) sdot += (double)h2f(m->wcls[(size_t)v * dim + i]) * xb[i];
+        logits_out[v] = sdot;
+    }
+    free(x); free(xb); free(q); free(hb); free(hb2); free(att);
+    return 0;
 }
 
 /* greedy decode, generate() llama2_q4.cu:436-482 with run_transformer :346-395 and

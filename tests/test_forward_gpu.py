@@ -152,3 +152,24 @@ def test_bench_in_network_times_the_products_own_launches(q4, models):
     avg_all, _, _, n_all = t.bench_in_network(1 | 2 | 4 | 8 | 16, tokens=1)
     assert n_all == 5 * t.config.n_layers and avg_all > 0
     t.close()
+
+
+@pytest.mark.parametrize("name", ["small", "tiny_gqa"])
+def test_gpu_is_as_close_to_unrounded_arithmetic_as_the_restatement(q4, orc, models, name):
+    """Both fp16 evaluations (HIP path, reference-order restatement) against the double, never-rounded forward of the
+    same network: the HIP path's error must be of the restatement's size (<= 2x + 1e-3), position by position."""
+    t = q4.Transformer(models[name])
+    m = orc.Model(models[name])
+    prompt = [1, 400, 22, 7, 513, 99]
+    t.reset(prompt)
+    for pos, tok in enumerate(prompt):
+        t.run_transformer(False)
+        q4.synchronize()
+        g = t.logits().astype(np.float64)
+        r = m.forward(tok, pos).astype(np.float64)
+        e = m.forward_f64(tok, pos, cap=8)
+        den = np.maximum(1.0, np.abs(e))
+        eg, er = np.max(np.abs(g - e) / den), np.max(np.abs(r - e) / den)
+        assert eg <= 2.0 * er + 1e-3, (pos, eg, er)
+    t.close()
+    m.close()

@@ -99,3 +99,19 @@ def test_sampler_restatement_basic(orc, rng):
     L = orc.lib()
     assert L.orc_sample_topp(orc.f16_bits(logits.copy()), n, 1.0, 0.9, 0.5) == 77
     assert L.orc_sample_topp(orc.f16_bits(logits.copy()), n, 1.0, 1.0, 0.5) == 77
+
+
+def test_unrounded_f64_forward_brackets_the_restatement(tmp_path):
+    """orc_forward_f64 (double everywhere) and the reference-order fp16 restatement evaluate the same function: on a
+    shallow model they agree to fp16 noise, token for token."""
+    from llama_cu_awq_amd import synth
+    import oracle
+    p = str(tmp_path / "tiny.bin")
+    synth.write_model(p, "tiny", seed=11)
+    m = oracle.Model(p)
+    toks = [1, 40, 22, 7, 51, 9]
+    for pos, t in enumerate(toks):
+        a = m.forward(t, pos).astype(np.float64)
+        b = m.forward_f64(t, pos, cap=8)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 5e-3
+    m.close()
