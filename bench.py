@@ -160,6 +160,9 @@ def main():
             tr.bench_kernel(kid, 32)   # warm
             avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
             kernels[name] = {"us": round(avg, 3), "min_us": round(mn, 3), "bytes": nbytes, "GBps": round(nbytes / avg / 1e3, 1)}
+            if kid in (1, 2):   # BASELINE config 1, the single int4 GEMV: back-to-back calls inside one hipGraph over the ring
+                g = tr.bench_kernel_graph(kid, 32, 20)
+                kernels[name].update({"graph_us_per_call": round(g, 3), "graph_GBps": round(nbytes / g / 1e3, 1)})
         # the roofline kernel's duration is taken where the token loop runs it: eager decode steps of the same
         # network from position 64 on, dispatch timestamps (HIP events on the launch stream) on every gate/up launch
         tr.reset(PROMPT_IDS)
@@ -245,7 +248,20 @@ def main():
                                           "cpu_restatement_rms_err": round(float(np.sqrt(np.mean((r64 - exact) ** 2))), 5),
                                           "argmax_equal": bool(int(np.argmax(g64)) == int(np.argmax(exact))),
                                           "seconds": round(time.perf_counter() - t64, 1)}
+        # config 1 beside it: the restated single int4 GEMV 4096 -> 11008 on the host cores (median of 20 calls)
+        from llama_cu_awq_amd import synth as _synth
+        rng = np.random.default_rng(20240229)
+        gw, gz, gs = _synth.random_qweight(rng, cfg.dim, cfg.hidden_dim)
+        gx = rng.standard_normal(cfg.dim).astype(np.float16)
+        gt = []
+        for _ in range(20):
+            tg = time.perf_counter()
+            oracle.matmul_q4(gx, gw, gz, gs, cfg.dim, cfg.hidden_dim)
+            gt.append(time.perf_counter() - tg)
+        gemv_cpu_us = 1e6 * float(np.median(gt))
         cpu = {"value": round(n_done / cpu_secs, 4), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+               "single_gemv": {"shape": "%d->%d" % (cfg.dim, cfg.hidden_dim), "us": round(gemv_cpu_us, 1),
+                               "GBps": round(kb[1][1] / gemv_cpu_us / 1e3, 2)},
                "sample": "%d decode steps (positions 0..%d) of the same %s checkpoint, CPU restatement of run_llama_network "
                          "(oracle/q4_oracle.c, OpenMP); the reference has no CPU path" % (n_done, n_done - 1, args.model)}
         m.close()

@@ -126,3 +126,24 @@ def test_argmax(q4, orc, rng, size):
     q4.check(q4.lib().q4_argmax(dx.ptr, size, ring.ptr, hpos.ptr, dpos.ptr, 0))   # prompt phase: only advance pos
     q4.synchronize()
     assert ring.get(np.int32)[6] == 0 and hpos.get(np.int32)[0] == 6
+
+
+@pytest.mark.parametrize("with_scratch", [False, True])
+def test_attention_16k_context(q4, orc, rng, with_scratch):
+    """contexts past the reference's 8192-position shared-memory softmax (softmax_kernel_no_smem,
+    gpu_kernels.h:403-446): 16384-position cache, GQA (kv_mul 2), both the one-block-per-head kernel (scores in LDS)
+    and the split-context kernels (partials in the `att` scratch)."""
+    heads, kv_mul, hs, pos, seq = 8, 2, 128, 16000, 16384
+    dim, kv_dim = heads * hs, heads * hs // kv_mul
+    q = rng.standard_normal(dim).astype(np.float16)
+    kc = (0.5 * rng.standard_normal(seq * kv_dim)).astype(np.float16)
+    vc = rng.standard_normal(seq * kv_dim).astype(np.float16)
+    ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos)
+    dq, dk, dv, do = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(vc), q4.DevBuf(nbytes=dim * 2)
+    dpos = q4.DevBuf(np.array([pos], dtype=np.int32))
+    att = q4.DevBuf(nbytes=heads * max(seq, dim) * 2 * 2) if with_scratch else None
+    q4.check(q4.lib().q4_multi_head_attention(do.ptr, dq.ptr, dk.ptr, dv.ptr, att.ptr if att else None, heads, hs, kv_mul, seq, dpos.ptr))
+    q4.synchronize()
+    got = do.get(np.float16, dim)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), err.max()
