@@ -1,19 +1,25 @@
 // q4_sampling.hip -- temperature / top-p sampling: sample() sampler.h:51-81 with softmax_logits_kernel
 // (gpu_kernels.h:499-550) and sample_top_p_kernel (:555-584). The reference leans on cub::DeviceRadixSort and
-// cub::DeviceScan; here:
-//   * softmax_logits: one 1024-thread block, the same fp16 rounding points (logits/T, exp, normalise); sums are a
-//     balanced pairwise tree over the 1024 per-thread partials (cub's order is unspecified; the oracle restates this one)
-//   * sort: single-block stable LSD radix sort of the fp16 probabilities (non-negative -> bit pattern is monotonic),
-//     4 passes of 4 bits, descending, ties keep ascending index (what cub's stable SortPairsDescending yields)
-//   * prefix sum + threshold search fused: the reference's inclusive scan accumulates IN FP16 and the search wants the
-//     first index whose prefix reaches the threshold, so one lane walks the sorted probabilities with an fp16
-//     accumulator and stops at the hit (a few dozen steps for top-p 0.6-0.9; vocab steps worst case).
+// cub::DeviceScan (7+ launches); here ONE 1024-thread block does the whole step with the same fp16 rounding points:
+//   * softmax: logits/T, exp, normalise rounded to fp16 exactly where the reference stores them; the vocabulary
+//     lives in registers (32 strided elements per thread) between the phases; sums are a balanced pairwise tree over
+//     the 1024 per-thread partials (cub's order is unspecified; the oracle restates this one)
+//   * sort: stable LSD radix sort of the fp16 probabilities (non-negative -> the bit pattern is monotonic), two passes of
+//     8 bits, descending, ties keep ascending index (what cub's stable SortPairsDescending yields). Each wave owns a
+//     contiguous segment and ranks 64 keys at a time with ballot matching, so loads are coalesced and the order is
+//     deterministic (no atomics)
+//   * inclusive prefix sum IN FP16 (sampler.h:72-78) in a fixed cub-shaped order -- thread-sequential over 1/1024th of
+//     the vocabulary, Hillis-Steele across the 64 lanes, sequential across the 16 waves, every add rounded to fp16 --
+//     and the first index whose prefix reaches the threshold (:566-577). cub's order is unspecified; the oracle
+//     restates this one.
 #include <hip/hip_runtime.h>
 #include "q4_device.h"
 #include "q4_internal.h"
 using namespace q4;
 
 namespace {
+
+constexpr int SMP_T = 1024, SMP_W = 16, SMP_E = 32;   // threads, waves, register-resident elements per thread
 
 __device__ __forceinline__ float block_tree_sum(float v, float* red) {   // red: 16 floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -32,132 +38,309 @@ __device__ __forceinline__ float block_tree_max(float v, float* red) {
     return row16_max(red[lane & 15]);
 }
 
-__global__ void __launch_bounds__(1024) softmax_logits_kernel(q4_half* logits, int size, float temperature, int* indices) {
-    __shared__ float red[16];
-    const int tid = threadIdx.x, step = blockDim.x;
-    for (int t = tid; t < size; t += step) {
-        indices[t] = t;                                        // gpu_kernels.h:507
-        float val = h2f(logits[t]);
-        val /= temperature;                                    // :511
-        logits[t] = f2h(val);
+// softmax_logits_kernel gpu_kernels.h:499-550, in place on `logits`, indices[t] = t (:507)
+__device__ void softmax_phase(q4_half* __restrict__ logits, int size, float temperature, int* __restrict__ indices, float* red) {
+    const int tid = threadIdx.x;
+    if (size <= SMP_T * SMP_E) {
+        float v[SMP_E];
+#pragma unroll
+        for (int k = 0; k < SMP_E; k++) {
+            const int t = tid + k * SMP_T;
+            float val = t < size ? h2f(logits[t]) : 0.f;
+            val /= temperature;                                    // :511
+            v[k] = round_h(val);
+        }
+        float max_val = -3.402823466e+38f;                         // :522
+#pragma unroll
+        for (int k = 0; k < SMP_E; k++)
+            if (tid + k * SMP_T < size) max_val = fmaxf(max_val, v[k]);
+        max_val = block_tree_max(max_val, red);
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SMP_E; k++)
+            if (tid + k * SMP_T < size) {
+                const float e = expf(v[k] - max_val);              // :536
+                v[k] = round_h(e);
+                sum += e;
+            }
+        sum = block_tree_sum(sum, red);
+#pragma unroll
+        for (int k = 0; k < SMP_E; k++) {
+            const int t = tid + k * SMP_T;
+            if (t < size) { logits[t] = f2h(v[k] / sum); indices[t] = t; }   // :549
+        }
+    } else {   // larger vocabularies: the same arithmetic through memory
+        for (int t = tid; t < size; t += SMP_T) {
+            indices[t] = t;
+            float val = h2f(logits[t]);
+            val /= temperature;
+            logits[t] = f2h(val);
+        }
+        __syncthreads();
+        float max_val = -3.402823466e+38f;
+        for (int i = tid; i < size; i += SMP_T) max_val = fmaxf(max_val, h2f(logits[i]));
+        max_val = block_tree_max(max_val, red);
+        float sum = 0.0f;
+        for (int i = tid; i < size; i += SMP_T) {
+            const float e = expf(h2f(logits[i]) - max_val);
+            logits[i] = f2h(e);
+            sum += e;
+        }
+        sum = block_tree_sum(sum, red);
+        for (int t = tid; t < size; t += SMP_T) logits[t] = f2h(h2f(logits[t]) / sum);
     }
     __syncthreads();
-    float max_val = tid < size ? h2f(logits[tid]) : -3.402823466e+38f;   // :522
-    for (int i = tid + step; i < size; i += step) max_val = fmaxf(max_val, h2f(logits[i]));
-    max_val = block_tree_max(max_val, red);
-    float sum = 0.0f;
-    for (int i = tid; i < size; i += step) {
-        const float v = expf(h2f(logits[i]) - max_val);        // :536
-        logits[i] = f2h(v);
-        sum += v;
-    }
-    sum = block_tree_sum(sum, red);
-    for (int t = tid; t < size; t += step) logits[t] = f2h(h2f(logits[t]) / sum);   // :549
 }
 
-// one pass of the stable LSD radix sort: 4-bit digit at `shift`, descending (digit' = 15 - digit)
-__global__ void __launch_bounds__(1024) radix_pass_kernel(const uint16_t* kin, const int* vin, uint16_t* kout, int* vout, int n,
-                                                          int shift) {
-    __shared__ unsigned cnt[16 * 1024];       // [digit][thread]
-    __shared__ unsigned wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(n, lo + chunk);
-    unsigned c[16];
+// lanes of this wave (among `valid` ones) holding the same 8-bit digit
+__device__ __forceinline__ unsigned long long match8(unsigned d, bool valid) {
+    unsigned long long m = __ballot(valid);
 #pragma unroll
-    for (int d = 0; d < 16; d++) c[d] = 0;
-    for (int i = lo; i < hi; i++) {
-        const int d = 15 - ((kin[i] >> shift) & 15);
-#pragma unroll
-        for (int e = 0; e < 16; e++) c[e] += (e == d);
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
     }
-#pragma unroll
-    for (int d = 0; d < 16; d++) cnt[d * 1024 + tid] = c[d];
+    return m;
+}
+
+// one stable pass, 8-bit digit at `shift`, descending (digit' = 255 - digit), through global memory (vocabularies
+// above 32 x 1024 entries). vin == nullptr: value = index. cnt: [256][16] counters (digit-major, wave-minor), wtot: [16]
+__device__ void radix_pass(const uint16_t* __restrict__ kin, const int* __restrict__ vin, uint16_t* __restrict__ kout,
+                           int* __restrict__ vout, int n, int shift, volatile unsigned* cnt, unsigned* wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = ((n + SMP_T - 1) / SMP_T) * 64;              // keys per wave segment
+    const int seg0 = wave * S;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i = tid; i < 256 * SMP_W; i += SMP_T) cnt[i] = 0;
     __syncthreads();
-    // exclusive scan over the flattened [digit][thread] array: thread t owns entries 16t .. 16t+15
-    unsigned local[16], total = 0;
+    for (int it = 0; it < S; it += 64) {
+        const int i = seg0 + it + lane;
+        const bool valid = i < n;
+        const unsigned k = valid ? kin[i] : 0u;
+        const unsigned d = 255u - ((k >> shift) & 255u);
+        const unsigned long long m = match8(d, valid);
+        if (valid && (m & lt) == 0ull) cnt[d * SMP_W + wave] += (unsigned)__popcll(m);   // leader of its digit
+    }
+    __syncthreads();
+    unsigned a[4], tot = 0;                                    // exclusive scan, thread t owns counters 4t .. 4t+3
 #pragma unroll
-    for (int e = 0; e < 16; e++) { local[e] = cnt[tid * 16 + e]; total += local[e]; }
-    unsigned incl = total;                                   // wave inclusive scan
+    for (int e = 0; e < 4; e++) { a[e] = cnt[tid * 4 + e]; tot += a[e]; }
+    unsigned incl = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
     }
-    if (lane == 63) wsum[wave] = incl;
+    if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wave; w++) base += wsum[w];
-    unsigned run = base + incl - total;
+    unsigned run = incl - tot;
+    for (int w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { cnt[tid * 4 + e] = run; run += a[e]; }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; e++) { cnt[tid * 16 + e] = run; run += local[e]; }
-    __syncthreads();
-    unsigned off[16];
-#pragma unroll
-    for (int d = 0; d < 16; d++) off[d] = cnt[d * 1024 + tid];
-    for (int i = lo; i < hi; i++) {
-        const uint16_t k = kin[i];
-        const int d = 15 - ((k >> shift) & 15);
-        unsigned dst = 0;
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            if (e == d) dst = off[e]++;
-        kout[dst] = k;
-        vout[dst] = vin[i];
+    for (int it = 0; it < S; it += 64) {
+        const int i = seg0 + it + lane;
+        const bool valid = i < n;
+        const unsigned k = valid ? kin[i] : 0u;
+        const int v = valid ? (vin ? vin[i] : i) : 0;
+        const unsigned d = 255u - ((k >> shift) & 255u);
+        const unsigned long long m = match8(d, valid);
+        const unsigned rank = (unsigned)__popcll(m & lt);
+        if (valid) {
+            const unsigned pos = cnt[d * SMP_W + wave] + rank;   // every lane reads before the leader's update below
+            kout[pos] = (uint16_t)k;
+            vout[pos] = v;
+        }
+        if (valid && rank == 0) cnt[d * SMP_W + wave] += (unsigned)__popcll(m);
     }
+    __syncthreads();
 }
 
-// sample_top_p_kernel gpu_kernels.h:555-584 fused with the fp16 inclusive scan (sampler.h:72-78)
-__global__ void sample_scan_kernel(const uint16_t* probs, const int* indices, int n, float threshold, int* result,
-                                   volatile int* pPos, int* pPosGpu) {
-    if (threadIdx.x != 0) return;
-    float run = 0.f;
-    int min_index = n - 1;
-    for (int t = 0; t < n; t++) {
-        run = round_h(run + h2f(probs[t]));              // fp16 accumulator
-        if (run >= threshold) { min_index = t; break; }
+// The same pass for vocabularies of up to 32 x 1024 entries, entirely on chip: the wave's segment sits in registers as
+// key << 16 | index (kv), the output is scattered into a 128 KB LDS buffer (a single CU issues one scattered global
+// line per cycle -- 58 us per pass for 2 x 32000 stores -- while LDS takes the same scatter in ~2 us).
+// DSH / DBITS: position and width of the digit inside kv. TRANSPOSE: final pass, element `pos` goes to buf[(pos % E) * 1024 + pos / E]
+// so that thread t of the scan phase finds its E consecutive entries at stride 1024 (conflict-free reads).
+template <int DSH, int DBITS, bool TRANSPOSE>
+__device__ void radix_pass_lds(const unsigned (&kv)[SMP_E], int n, int S, int E, unsigned* buf, volatile unsigned* cnt,
+                               unsigned* wtot) {
+    constexpr unsigned DMASK = (1u << DBITS) - 1u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg0 = wave * S;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i = tid; i < 256 * SMP_W; i += SMP_T) cnt[i] = 0;
+    __syncthreads();
+    // walk 1: rank every key among the equal digits of its wave segment (ballot matching, 64 keys at a time) and count;
+    // the rank (< 2048) is kept, two per register, so that the scattering walk needs no second matching
+    unsigned loc[SMP_E / 2];
+#pragma unroll
+    for (int j = 0; j < SMP_E; j++) {
+        unsigned l = 0;
+        if (j * 64 < S) {
+            const bool valid = seg0 + j * 64 + lane < n;
+            const unsigned d = DMASK - ((kv[j] >> DSH) & DMASK);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < DBITS; b++) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const unsigned rank = (unsigned)__popcll(m & lt);
+            if (valid) {
+                const unsigned before = cnt[d * SMP_W + wave];   // every lane reads before the leader's update below
+                l = before + rank;
+                if (rank == 0) cnt[d * SMP_W + wave] = before + (unsigned)__popcll(m);
+            }
+        }
+        if (j & 1) loc[j >> 1] |= l << 16; else loc[j >> 1] = l;
     }
-    int token_pos = *pPosGpu;                            // == *pPos (:579-580) without the PCIe read
-    token_pos++;
-    result[token_pos] = indices[min_index];              // :578
-    __threadfence_system();                              // the host may be spinning on *pPos (q4_wait_pos)
-    *pPos = token_pos;
-    *pPosGpu = token_pos;
+    __syncthreads();
+    unsigned a[4], tot = 0;                                    // exclusive scan, thread t owns counters 4t .. 4t+3
+#pragma unroll
+    for (int e = 0; e < 4; e++) { a[e] = cnt[tid * 4 + e]; tot += a[e]; }
+    unsigned incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - tot;
+    for (int w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { cnt[tid * 4 + e] = run; run += a[e]; }
+    __syncthreads();
+    const bool pow2 = (E & (E - 1)) == 0;
+    const int esh = 31 - __clz(E);
+#pragma unroll
+    for (int j = 0; j < SMP_E; j++)
+        if (j * 64 < S && seg0 + j * 64 + lane < n) {
+            const unsigned d = DMASK - ((kv[j] >> DSH) & DMASK);
+            unsigned pos = cnt[d * SMP_W + wave] + ((loc[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+            if (TRANSPOSE) {
+                const unsigned t = pow2 ? pos >> esh : pos / (unsigned)E;
+                pos = (pos - t * (unsigned)E) * SMP_T + t;
+            }
+            buf[pos] = kv[j];
+        }
+    __syncthreads();
+}
+
+// fp16 inclusive prefix sum in the fixed order of the header + first index with prefix >= threshold, left in *hit
+// (LDS, initialised to INT_MAX by the caller before a barrier). key(i): fp16 bits of the i-th probability.
+template <typename KeyAt>
+__device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot, int* hit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = (n + SMP_T - 1) / SMP_T;
+    const int lo = tid * E, hi = min(n, lo + E);
+    float total = 0.f;
+    for (int i = lo; i < hi; i++) total = round_h(total + h2f(key(i, i - lo)));
+    float v = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(v, off);
+        if (lane >= off) v = round_h(v + o);
+    }
+    if (lane == 63) wtot[wave] = v;
+    __syncthreads();
+    float base = 0.f;
+    for (int w = 0; w < wave; w++) base = round_h(base + wtot[w]);
+    const float prev = __shfl_up(v, 1);
+    const float excl = lane > 0 ? round_h(base + prev) : base;
+    float r = 0.f;
+    for (int i = lo; i < hi; i++) {
+        r = round_h(r + h2f(key(i, i - lo)));
+        if (round_h(excl + r) >= threshold) { atomicMin(hit, i); break; }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int n, float temperature, int do_sort,
+                                                          float threshold, int* indices, uint16_t* k0, int* v0,
+                                                          uint16_t* k1, int* v1, int* result, volatile int* pPos,
+                                                          int* pPosGpu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dyn[];   // [32768] sort buffer (on-chip path) + [4096] counters
+    __shared__ float red[16];
+    __shared__ unsigned wtot[16];
+    __shared__ int hit;
+    const bool onchip = n <= SMP_T * SMP_E;
+    unsigned* buf = dyn;
+    unsigned* cnt = onchip ? dyn + SMP_T * SMP_E : dyn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) hit = 0x7fffffff;
+    softmax_phase(logits, n, temperature, indices, red);                         // sampler.h:53
+    const int E = (n + SMP_T - 1) / SMP_T;
+    int token = 0;
+    if (!do_sort) {                                                              // sampler.h:57-59
+        const uint16_t* keys = logits;
+        scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
+        if (tid == 0) token = hit == 0x7fffffff ? n - 1 : hit;                   // indices[t] == t
+    } else if (onchip) {                                                         // sampler.h:60-69
+        const int S = E * 64, seg0 = wave * S;
+        unsigned kv[SMP_E];
+#pragma unroll
+        for (int j = 0; j < SMP_E; j++) {
+            const int i = seg0 + j * 64 + lane;
+            const bool valid = j * 64 < S && i < n;
+            kv[j] = valid ? ((unsigned)logits[i] << 16) | (unsigned)i : 0u;
+        }
+        radix_pass_lds<16, 7, false>(kv, n, S, E, buf, cnt, wtot);   // key bits 0-6
+#pragma unroll
+        for (int j = 0; j < SMP_E; j++) {
+            const int i = seg0 + j * 64 + lane;
+            kv[j] = (j * 64 < S && i < n) ? buf[i] : 0u;
+        }
+        __syncthreads();                                                         // all segments are in registers
+        radix_pass_lds<23, 8, true>(kv, n, S, E, buf, cnt, wtot);     // key bits 7-14 (bit 15 is the sign: 0)
+        scan_search_phase([&](int, int j) { return (uint16_t)(buf[j * SMP_T + tid] >> 16); }, n, threshold, red, &hit);
+        if (tid == 0) {
+            const int mi = hit == 0x7fffffff ? n - 1 : hit;                      // gpu_kernels.h:560,574
+            const int t = mi / E;
+            token = (int)(buf[(mi - t * E) * SMP_T + t] & 0xffffu);
+        }
+    } else {
+        radix_pass(logits, nullptr, k0, v0, n, 0, cnt, wtot);
+        radix_pass(k0, v0, k1, v1, n, 8, cnt, wtot);
+        const uint16_t* keys = k1;
+        scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
+        if (tid == 0) token = v1[hit == 0x7fffffff ? n - 1 : hit];
+    }
+    if (tid == 0) {
+        int token_pos = *pPosGpu;                            // == *pPos (:579-580) without the PCIe read
+        token_pos++;
+        result[token_pos] = token;                           // :578
+        __threadfence_system();                              // the host may be spinning on *pPos (q4_wait_pos)
+        *pPos = token_pos;
+        *pPosGpu = token_pos;
+    }
 }
 
 }  // namespace
 
 extern "C" int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin) {
     const int n = sampler->vocab_size;
-    Q4_LAUNCH(softmax_logits_kernel, dim3(1), dim3(1024), 0, s->logits, n, sampler->temperature, sampler->indices);   // sampler.h:53
-    Q4_LAUNCH_CHECK();
-    float threshold;
-    const uint16_t* keys = s->logits;
-    const int* vals = sampler->indices;
-    if (sampler->topp <= 0 || sampler->topp >= 1) {
-        threshold = coin;                                                           // sampler.h:57-59
-    } else {
-        if (sampler->temp_storage_bytes_sort == 0) {                                // :62-66 (lazy scratch)
-            const size_t bytes = 2 * ((size_t)n * sizeof(uint16_t) + 256) + 2 * ((size_t)n * sizeof(int) + 256);
-            Q4_HIP(hipMalloc(&sampler->tempStorage_sort, bytes));
-            sampler->temp_storage_bytes_sort = bytes;
-        }
-        char* base = (char*)sampler->tempStorage_sort;
-        const size_t kb = ((size_t)n * sizeof(uint16_t) + 255) / 256 * 256, vb = ((size_t)n * sizeof(int) + 255) / 256 * 256;
-        uint16_t* k0 = (uint16_t*)base; uint16_t* k1 = (uint16_t*)(base + kb);
-        int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
-        Q4_LAUNCH(radix_pass_kernel, dim3(1), dim3(1024), 0, (const uint16_t*)s->logits, (const int*)sampler->indices, k0, v0, n, 0);
-        Q4_LAUNCH(radix_pass_kernel, dim3(1), dim3(1024), 0, (const uint16_t*)k0, (const int*)v0, k1, v1, n, 4);
-        Q4_LAUNCH(radix_pass_kernel, dim3(1), dim3(1024), 0, (const uint16_t*)k1, (const int*)v1, k0, v0, n, 8);
-        Q4_LAUNCH(radix_pass_kernel, dim3(1), dim3(1024), 0, (const uint16_t*)k0, (const int*)v0, k1, v1, n, 12);
-        Q4_LAUNCH_CHECK();
-        keys = k1;
-        vals = v1;
-        threshold = coin * sampler->topp;                                           // sampler.h:69
+    const int do_sort = !(sampler->topp <= 0 || sampler->topp >= 1);
+    const float threshold = do_sort ? coin * sampler->topp : coin;                   // sampler.h:57-59,69
+    if (sampler->temp_storage_bytes_sort == 0) {                                    // :62-66 (lazy scratch)
+        const size_t bytes = 2 * ((size_t)n * sizeof(uint16_t) + 256) + 2 * ((size_t)n * sizeof(int) + 256);
+        Q4_HIP(hipMalloc(&sampler->tempStorage_sort, bytes));
+        sampler->temp_storage_bytes_sort = bytes;
     }
-    Q4_LAUNCH(sample_scan_kernel, dim3(1), dim3(64), 0, keys, vals, n, threshold, &(s->shared_data->tokens[0]),
-              &(s->shared_data->pos), s->pos);                                      // :80
+    char* base = (char*)sampler->tempStorage_sort;
+    const size_t kb = ((size_t)n * sizeof(uint16_t) + 255) / 256 * 256, vb = ((size_t)n * sizeof(int) + 255) / 256 * 256;
+    uint16_t* k0 = (uint16_t*)base; uint16_t* k1 = (uint16_t*)(base + kb);
+    int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
+    const size_t smem = (n <= SMP_T * SMP_E ? (size_t)SMP_T * SMP_E * 4 : 0) + 256 * SMP_W * 4;
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
+        lds_opt_in = true;
+    }
+    Q4_LAUNCH(topp_sample_kernel, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, threshold,
+              sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos);   // :53-80
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }

@@ -421,7 +421,7 @@ static float pairwise_sum(const float *v, int n) {
  * softmax_logits_kernel (fp16 rounding at: logits/temperature, exp, normalise),
  * descending sort of fp16 probabilities (cub radix sort is stable: equal keys keep
  * ascending index order), fp16 inclusive prefix sum (order of cub DeviceScan is
- * unspecified; restated sequentially in fp32 with fp16 rounding of each output),
+ * unspecified; restated in the fixed thread/lane/wave order documented below),
  * first index whose prefix >= threshold (else n-1). Returns the token id. */
 static int cmp_desc_stable(const void *a, const void *b) {
     const uint32_t *pa = (const uint32_t *)a, *pb = (const uint32_t *)b;
@@ -448,12 +448,36 @@ int orc_sample_topp(f16 *logits, int n, float temperature, float topp, float coi
     float threshold;
     if (topp <= 0 || topp >= 1) threshold = coin;
     else { qsort(kv, n, 8, cmp_desc_stable); threshold = coin * topp; }
-    float run = 0.f;
-    int min_index = n - 1;
-    for (int t = 0; t < n; t++) {
-        run = h2f(f2h(run + h2f((f16)kv[2 * t])));
-        if (run >= threshold) { min_index = t; break; }
+    /* fp16 inclusive prefix sum in the HIP kernel's fixed, cub-shaped order (cub::DeviceScan's own order is
+     * unspecified): 1024 "threads" each sum their E consecutive entries sequentially, a Hillis-Steele scan runs over the
+     * 64 lanes of each of the 16 "waves", the wave totals are added sequentially; every add rounds to fp16 (sampler.h:72-78
+     * scans `half`). Then the first index whose prefix >= threshold, else n-1 (gpu_kernels.h:560-577). */
+    int E = (n + 1023) / 1024;
+    float tot[1024], v[1024], wt[16];
+    for (int t = 0; t < 1024; t++) {
+        float r = 0.f;
+        for (int i = t * E; i < n && i < t * E + E; i++) r = h2f(f2h(r + h2f((f16)kv[2 * i])));
+        tot[t] = r;
+        v[t] = r;
     }
+    for (int off = 1; off < 64; off <<= 1) {
+        float nv[1024];
+        for (int t = 0; t < 1024; t++) nv[t] = (t % 64) >= off ? h2f(f2h(v[t] + v[t - off])) : v[t];
+        memcpy(v, nv, sizeof(v));
+    }
+    for (int w = 0; w < 16; w++) wt[w] = v[w * 64 + 63];
+    int min_index = n - 1;
+    for (int t = 0; t < 1024 && min_index == n - 1; t++) {
+        float base = 0.f;
+        for (int w = 0; w < t / 64; w++) base = h2f(f2h(base + wt[w]));
+        float excl = (t % 64) > 0 ? h2f(f2h(base + v[t - 1])) : base;
+        float r = 0.f;
+        for (int i = t * E; i < n && i < t * E + E; i++) {
+            r = h2f(f2h(r + h2f((f16)kv[2 * i])));
+            if (h2f(f2h(excl + r)) >= threshold) { min_index = i; break; }
+        }
+    }
+    (void)tot;
     int tok = (int)kv[2 * min_index + 1];
     free(kv);
     return tok;

@@ -80,6 +80,7 @@ def _parse(argv):
     arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
     out = api.CliArgs()
     rc = api.lib().q4_parse_args(len(argv), arr, C.byref(out))
+    out._argv_keepalive = arr      # the parsed struct points into argv, like the reference's main()
     return rc, out
 
 
