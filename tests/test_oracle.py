@@ -115,3 +115,29 @@ def test_unrounded_f64_forward_brackets_the_restatement(tmp_path):
         b = m.forward_f64(t, pos, cap=8)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 5e-3
     m.close()
+
+
+@pytest.mark.parametrize("n,temperature,topp", [(1000, 1.0, 0.9), (32000, 0.5, 0.6), (32000, 1.0, 0.9), (4097, 0.7, 1.0)])
+def test_topp_restatement_against_plain_numpy(n, temperature, topp):
+    """The restated sampler (fp16 rounding points, fixed-order fp16 prefix scan) against the textbook float64 form:
+    sort descending, cumulative sum, first index reaching coin*topp. They may only disagree where the cumulative
+    probability is within fp16 accumulation error of the threshold."""
+    import oracle
+    rng = np.random.default_rng(n + int(100 * temperature))
+    logits = (3.0 * rng.standard_normal(n)).astype(np.float16)
+    x = (logits.astype(np.float32) / np.float32(temperature)).astype(np.float16).astype(np.float64)
+    e = np.exp(x - x.max())
+    p = (e / e.sum())
+    order = np.lexsort((np.arange(n), -p.astype(np.float16).astype(np.float64))) if 0 < topp < 1 else np.arange(n)
+    cum = np.cumsum(p[order])
+    agree = 0
+    for coin in (0.03, 0.2, 0.41, 0.77, 0.93):
+        thr = coin * topp if 0 < topp < 1 else coin
+        tok = oracle.lib().orc_sample_topp(oracle.f16_bits(logits.copy()), n, temperature, topp, coin)
+        k = int(np.searchsorted(cum, thr, side="left"))
+        pos = int(np.nonzero(order == tok)[0][0])
+        # fp16 accumulation: the restated prefix at `pos` may be off by ~1e-2 relative from the exact cumulative sum
+        lo = cum[pos - 1] if pos > 0 else 0.0
+        assert lo - 2e-2 <= thr <= cum[pos] + 2e-2 or pos == n - 1, (coin, pos, k, lo, cum[pos], thr)
+        agree += pos == min(k, n - 1)
+    assert agree >= 2
