@@ -675,10 +675,11 @@ float q4_perplexity_ids(Transformer* t, Sampler* sampler, const int* tokens_with
     if (!state->logits_array || num_tokens < 1) return -1.0f;
     if (num_tokens >= config->seq_len) num_tokens = config->seq_len - 1;           // :68-72
     if (q4_reset_sequence(state, tokens_with_bos, num_tokens + 1)) return -1.0f;   // :76-78
-    for (int pos = 0; pos < num_tokens; pos++) {
-        if (q4_run_transformer(0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
-        if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                    // :81
-    }
+    // the input tokens are all known: the steps are queued back to back (the device advances its own position) and the
+    // host synchronises once, where the reference calls cudaDeviceSynchronize after every step (:81)
+    for (int pos = 0; pos < num_tokens; pos++)
+        if (q4_run_transformer_at(pos, 0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
+    if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                        // :81
     float* logits_arr = (float*)malloc((size_t)num_tokens * config->vocab_size * sizeof(float));
     if (q4_get_logits_array(t, num_tokens, logits_arr)) { free(logits_arr); return -1.0f; }   // :88-89
     float pplx = compute_perplexity(tokens_with_bos + 1, logits_arr, num_tokens, config->vocab_size);   // :91
