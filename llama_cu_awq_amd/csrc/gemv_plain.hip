@@ -4,11 +4,12 @@ namespace q4 {
 int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
 #define Q4_CASE(S, C) if (slots == S && cols == C) return launch_one<MODE_PLAIN, S, C, false>(a, waves);
     const int slots = pick_slots(a.nslots);
-    if (g_ksplit && slots > 0 && a.nslots >= 5) {   // long-K (down projection): two waves per column group (gemv_q4.h, KS)
-        const int sh = (a.nslots + 1) / 2;
+    if ((g_ksplit && a.nslots >= 5) || a.nslots > 8) {   // long-K (down projection): two waves per column group (gemv_q4.h, KS)
+        const int sh = (a.nslots + 1) / 2;               // up to 8: K <= 32768 (Llama-2-70B / CodeLlama-34B down projections)
 #define Q4_KS(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 2>(a, waves);
-        Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4)
+        Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4) Q4_KS(5) Q4_KS(6) Q4_KS(7) Q4_KS(8)
 #undef Q4_KS
+        return Q4_ERR_UNSUPPORTED_SIZE;
     }
     if (cols == 4 && slots <= 3 && divUp(a.N, 4 * waves) <= 320) {   // about one block per CU: every load first
         if (slots == 2) return launch_one<MODE_PLAIN, 2, 4, false, 5>(a, waves);

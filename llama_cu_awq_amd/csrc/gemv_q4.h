@@ -423,6 +423,14 @@ static int launch_one(const GemvArgs& a0, int waves) {
     }
     constexpr int TS = SLOTS * KS;
     const size_t smem = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
+    if (smem > 64 * 1024) {   // long-K split kernels stage up to 32768 inputs: opt in to the CU's 160 KB once
+        static bool opted = false;
+        if (!opted) {
+            Q4_HIP(hipFuncSetAttribute((const void*)gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            opted = true;
+        }
+    }
     Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>), grid, dim3(waves * 64), smem, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;

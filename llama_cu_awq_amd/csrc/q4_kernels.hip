@@ -521,7 +521,7 @@ static int fill_geom(GemvArgs& a, int K, int N) {
     if (K % 32) return Q4_ERR_UNSUPPORTED_SIZE;                   // packed height must be whole uint4
     QGeom g = make_geom(K, N);
     a.K = K; a.N = N; a.pw4 = g.pw4; a.pzh = g.pzh; a.sh = g.sh; a.nslots = g.nslots;
-    if (pick_slots(g.nslots) == 0) return Q4_ERR_UNSUPPORTED_SIZE;   // K > 16384: not instantiated
+    if (g.nslots > 16) return Q4_ERR_UNSUPPORTED_SIZE;               // K > 32768: not instantiated (plain GEMV; fused kernels: K <= 16384)
     return Q4_OK;
 }
 

@@ -33,6 +33,9 @@ GEOMETRIES = {
     "tiny_gqa": (256, 352, 2, 8, 2, 512, 64, 10000.0),
     "small": (512, 1408, 3, 8, 8, 1024, 320, 10000.0),
     "micro": (64, 96, 2, 2, 2, 128, 32, 10000.0),       # committed fixture tests/golden/micro_model.bin (~60 KB)
+    # Llama-2-70B / CodeLlama-34B traits at test size: GQA (kv_mul 4), head 128, down projection with K > 16384
+    # (the K-split kernel's long form), rope_theta 1e6
+    "longk_gqa": (1024, 20480, 2, 8, 2, 512, 128, 1000000.0),
 }
 
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     out = {}
-    for name in ("tiny", "tiny_gqa", "small"):
+    for name in ("tiny", "tiny_gqa", "small", "longk_gqa"):
         p = str(d / (name + ".bin"))
         synth.write_model(p, name, seed=7)
         out[name] = p
@@ -26,7 +26,7 @@ def _logit_close(gpu, ref):
     return np.abs(gpu - ref) <= 3e-2 * np.maximum(1.0, np.abs(ref))    # SURVEY 8c forward tolerance
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa"])
 @pytest.mark.parametrize("fusion,graphs", [(1, 1), (0, 1), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()

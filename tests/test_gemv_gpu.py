@@ -10,7 +10,8 @@ from llama_cu_awq_amd import synth
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 5120), (5120, 13824), (13824, 5120),
-          (256, 352), (352, 256), (2048, 64), (8192, 1024), (16384, 256), (32, 8)]
+          (256, 352), (352, 256), (2048, 64), (8192, 1024), (16384, 256), (32, 8),
+          (22016, 8192), (28672, 8192), (32768, 512)]      # CodeLlama-34B / Llama-2-70B down projections, the K limit
 
 
 def _mk(rng, K, N):
@@ -31,7 +32,7 @@ def test_matmul_q4_plain(q4, orc, rng, K, N):
     assert_close_f16(dout.get(np.float16, N), ref16, ref64, what="plain %dx%d" % (K, N))
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (352, 256)])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (352, 256), (28672, 8192)])
 def test_matmul_q4_accum(q4, orc, rng, K, N):
     w, z, s, x = _mk(rng, K, N)
     old = rng.standard_normal(N).astype(np.float16)
@@ -59,7 +60,7 @@ def test_matmul_q4_kv_addressing(q4, orc, rng):
     assert (got[: loff + pos * N] == 0).all() and (got[loff + (pos + 1) * N:] == 0).all()
 
 
-@pytest.mark.parametrize("K,N", [(4096, 11008), (5120, 13824), (256, 352)])
+@pytest.mark.parametrize("K,N", [(4096, 11008), (5120, 13824), (256, 352), (8192, 28672)])
 def test_ffn_matvec_silu(q4, orc, rng, K, N):
     g = synth.random_qweight(rng, K, N)
     u = synth.random_qweight(rng, K, N)
