@@ -48,6 +48,7 @@ struct GemvArgs {
     const q4_half* rms_w;   // non-null: x is the raw residual, rmsnorm it while staging
     const int* pPos;
     int K, N;               // input length, output columns (per matrix)
+    int N_kv;               // QKV with grouped-query attention: columns of the k and v matrices (0: same as N)
     int pw4, pzh, sh, nslots;
     int accum;              // PLAIN: out = half(float(out) + sum)
     int loff;               // PLAIN: -1 = none. QKV: KV-cache layer offset
@@ -131,6 +132,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     const int sbase = khalf * SLOTS;            // first k-slot of this wave
     const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
     const int mat0 = (MODE == MODE_QKV) ? blockIdx.y : 0;
+    // grouped-query attention: k and v have kv_dim < dim columns; the launch grid is sized for q, surplus blocks leave
+    const int N = (MODE == MODE_QKV && mat0 != 0 && a.N_kv > 0) ? a.N_kv : a.N;
+    if (MODE == MODE_QKV && (int)(blockIdx.x * (blockDim.x >> 6)) * COLS >= N) return;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ABL == 3) { ts[0] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }   // [6]: 100 MHz, same on every XCD
 
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     }
     int colc[COLS];   // clamped: loads stay in bounds, the store is skipped
 #pragma unroll
-    for (int c = 0; c < COLS; c++) colc[c] = col[c] < a.N ? col[c] : a.N - 1;
+    for (int c = 0; c < COLS; c++) colc[c] = col[c] < N ? col[c] : N - 1;
 
     // the position is fetched in front of everything else: hoisted next to its use, hipcc puts a vector load +
     // vmcnt(0) between the weight loads and the first dot product, and the per-slot waits are gone
@@ -192,9 +196,9 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 #pragma unroll
     for (int m = 0; m < NMAT; m++) {
         const GemvMat& M = a.m[mat0 + m];
-        rw[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.w, 0, a.N * a.pw4 * 16, 0x00020000);
-        rz[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.z, 0, a.N * a.pzh * 4, 0x00020000);
-        rs[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.s, 0, a.N * a.sh * 2, 0x00020000);
+        rw[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.w, 0, N * a.pw4 * 16, 0x00020000);
+        rz[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.z, 0, N * a.pzh * 4, 0x00020000);
+        rs[m] = __builtin_amdgcn_make_buffer_rsrc((void*)M.s, 0, N * a.sh * 2, 0x00020000);
     }
 #define Q4_ISSUE_SLOT(s)                                                                                          \
     {                                                                                                             \
@@ -320,7 +324,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
     if constexpr (MODE == MODE_PLAIN) {
         q4_half* out = a.out[0];
-        if (a.loff != -1) out += (size_t)a.loff + (size_t)pos_now * a.N;           // gpu_kernels.h:225-227
+        if (a.loff != -1) out += (size_t)a.loff + (size_t)pos_now * N;             // gpu_kernels.h:225-227
         if constexpr (COLS == 4) {
             float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;   // 2^20, exact
             const int n = wg * 4 + row;
@@ -329,7 +333,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
                 __syncthreads();
                 if (khalf == 0) tot += part[(wave + 1) * 4 + row];
             }
-            if (writer && khalf == 0 && n < a.N) {
+            if (writer && khalf == 0 && n < N) {
                 float r = tot;
                 if (a.accum) r += h2f(out[n]);                                      // :229-230
                 out[n] = f2h(r);                                                    // :231
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             const float w0 = reduce4_rows(colsum[0][0], colsum[0][2], colsum[0][4], colsum[0][6]) * 1048576.f;
             const float w1 = reduce4_rows(colsum[0][1], colsum[0][3], colsum[0][5], colsum[0][7]) * 1048576.f;
             const int n = wg * 8 + row * 2;
-            if (writer && n < a.N) {
+            if (writer && n < N) {
                 float r0 = w0, r1 = w1;
                 if (a.accum) { r0 += h2f(out[n]); r1 += h2f(out[n + 1]); }
                 h2 pk = {(f16_t)r0, (f16_t)r1};
@@ -363,11 +367,11 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
         val *= u;                                       // :272
         const bool wr = COLS == 4 ? writer : (lane & 31u) == 0;
-        if (wr && n < a.N) a.out[0][n] = f2h(val);
+        if (wr && n < N) a.out[0][n] = f2h(val);
     } else {   // MODE_QKV, COLS == 4: rows = pair0 first, pair1 first, pair0 second, pair1 second
         q4_half* out = a.out[mat0];
         const int pos = pos_now;
-        if (mat0 != 0) out += (size_t)a.loff + (size_t)pos * a.N;                   // gpu_kernels.h:251,253
+        if (mat0 != 0) out += (size_t)a.loff + (size_t)pos * N;                     // gpu_kernels.h:251,253
         const float mine = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;
         const int hp = a.head_size >> 1;
         const int p = wg * 2 + (row & 1);                // pair index of this row
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             }
             r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
-        if (writer && n < a.N) out[n] = f2h(r);
+        if (writer && n < N) out[n] = f2h(r);
     }
     if (ABL == 3 && a.dbg != nullptr && lane == 0) {
         ts[7] = __builtin_readcyclecounter();

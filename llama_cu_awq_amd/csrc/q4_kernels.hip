@@ -528,10 +528,11 @@ static int fill_geom(GemvArgs& a, int K, int N) {
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w, const QWeight* qw,
                      const QWeight* kw, const QWeight* vw, int dim, int kv_dim, int loff, const int* pPos,
                      int head_size, float rope_theta) {
-    if (dim != kv_dim) return Q4_ERR_ARG;
+    if (kv_dim > dim || (kv_dim & 7)) return Q4_ERR_ARG;
     GemvArgs a = {};
     int rc = fill_geom(a, dim, dim);
     if (rc) return rc;
+    a.N_kv = kv_dim == dim ? 0 : kv_dim;      // grouped-query attention (llama2_q4.cu:309-313 runs three GEMVs there)
     fill_mat(a.m[0], qw); fill_mat(a.m[1], kw); fill_mat(a.m[2], vw);
     a.out[0] = q; a.out[1] = kc; a.out[2] = vc;
     a.x = x; a.rms_w = rms_w; a.pPos = pPos; a.loff = loff;

@@ -375,8 +375,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
         const int loff = l * p->seq_len * kv_dim;                                                      // :303
-        if (g_fusion && dim == kv_dim) {
-            // rmsnorm (:300) + qkv (:307) + RoPE (:317) in one launch
+        if (g_fusion) {
+            // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
                                           dim, kv_dim, loff, pPos, head_size, p->rope_theta));
         } else {

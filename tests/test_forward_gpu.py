@@ -65,13 +65,16 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
         L.q4_set_use_graphs(1)
 
 
-def test_fused_equals_unfused_bits(q4, models):
-    """The fused sequence must reproduce the 1:1 kernel chain (same canonical reductions): identical logits."""
+@pytest.mark.parametrize("name", ["small", "tiny_gqa", "longk_gqa"])
+def test_fused_equals_unfused_bits(q4, models, name):
+    """The fused sequence must reproduce the 1:1 kernel chain (same canonical reductions): identical logits -- also
+    for grouped-query attention, where the reference runs three GEMVs (llama2_q4.cu:310-312) and the fused QKV launch
+    sizes its k/v part to kv_dim."""
     L = q4.lib()
     outs = []
     for fusion in (0, 1):
         L.q4_set_fusion(fusion)
-        t = q4.Transformer(models["small"])
+        t = q4.Transformer(models[name])
         t.reset([1, 5, 9])
         for pos in range(6):
             t.run_transformer(pos >= 2)
