@@ -29,6 +29,7 @@ GEOMETRIES = {
     # name: (dim, hidden, layers, heads, kv_heads, vocab, seq_len, rope_theta)
     "7b": (4096, 11008, 32, 32, 32, 32000, 2048, 10000.0),
     "13b": (5120, 13824, 40, 40, 40, 32000, 2048, 10000.0),
+    "mistral7b": (4096, 14336, 32, 32, 8, 32000, 2048, 1000000.0),   # GQA 4:1, the shape of Mistral-7B / CodeLlama-style models
     "tiny": (256, 352, 2, 4, 4, 512, 64, 10000.0),
     "tiny_gqa": (256, 352, 2, 8, 2, 512, 64, 10000.0),
     "small": (512, 1408, 3, 8, 8, 1024, 320, 10000.0),

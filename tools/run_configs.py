@@ -22,7 +22,7 @@ api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 which = sys.argv[1:] or ["13b", "7b-2048", "7b-ppl"]
 for cfg in which:
-    model, ntok = ("13b", 256) if cfg == "13b" else ("7b", 2048)
+    model, ntok = ("13b", 256) if cfg == "13b" else ("mistral7b", 256) if cfg == "mistral7b" else ("7b", 2048)
     path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
     if not os.path.exists(path):
         synth.write_model(path, model)
@@ -57,7 +57,7 @@ for cfg in which:
     res = [tr.generate_ids(PROMPT, ntok) for _ in range(2)]
     tps = max(r[1] for r in res)
     out = {"config": cfg, "tokens_per_s": round(tps, 1), "timed_tokens": res[0][2], "ms_per_token": round(1000.0 / tps, 4)}
-    if cfg == "13b":
+    if cfg in ("13b", "mistral7b"):
         m = oracle.Model(path)
         tr.reset(PROMPT)
         worst = 0.0
