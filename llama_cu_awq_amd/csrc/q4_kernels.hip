@@ -15,6 +15,8 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
 int g_ablate = 0;
 int g_ksplit = 1;
+int g_att_chunk = 256;       // positions per split-attention block (128 or 256)
+int g_att_split_min = 1024;  // smallest sequence-length bin that uses the split-context kernels
 unsigned long long* g_dbg = nullptr;
 // early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain). The
 // hold-back before the early loads (bits 8+, 128-cycle steps) is chosen per launch in launch_one(): with 21 waves per CU
@@ -128,14 +130,13 @@ __device__ __forceinline__ float row_sum(float v) {
 
 constexpr int ATT_NW = 16;   // waves per attention block (one block per head)
 
-template <int LPR>
-__global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
+template <int LPR, int U = 4, int NW = ATT_NW>
+__global__ void __launch_bounds__(NW * 64) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
                                                                 const q4_half* value_cache, int head_size, int kv_mul,
                                                                 int kv_dim, const int* pPos, float alpha, int lds_scores,
                                                                 unsigned long long* dbg) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
-    constexpr int U = 4;                   // wave instructions in flight per pass
-    constexpr int NW = ATT_NW;
+    // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
     if (dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
     constexpr int group = stride * U;                        // positions per block pass (256 for head 128)
     const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
     const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+    if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
     const int size = *pPos + 1;
     if (dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
@@ -292,14 +294,13 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_kernel(q4_half* output,
 // in the `att` scratch (RunState::att, the buffer the reference keeps its scores in); attention_combine_kernel merges
 // them: out = sum_s exp(m_s - M) acc_s / sum_s exp(m_s - M) l_s. Scores are still rounded through fp16 (:167);
 // the probabilities stay fp32 here (the reference rounds them to fp16, :400 -- a <= 2^-11 relative difference).
-constexpr int ATT_CHUNK = 256;
-template <int LPR>
+template <int LPR, int U>
 __global__ void __launch_bounds__(ATT_NW * 64) attention_split_kernel(float* partials, const q4_half* q, const q4_half* key_cache,
                                                                       const q4_half* value_cache, int head_size, int kv_mul,
                                                                       int kv_dim, const int* pPos, float alpha) {
-    constexpr int R = 64 / LPR, U = 4, NW = ATT_NW;
+    constexpr int R = 64 / LPR, NW = ATT_NW;
     constexpr int stride = NW * R;
-    static_assert(stride * U == ATT_CHUNK, "one chunk = one register-resident group");
+    constexpr int ATT_CHUNK = stride * U;                    // positions per block = one register-resident group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red_max = reinterpret_cast<float*>(smem);
     float* red_sum = red_max + 16;
@@ -564,6 +565,7 @@ extern "C" {
 
 void q4_set_ablate(int mode) { g_ablate = mode; }
 void q4_set_ksplit(int on) { g_ksplit = on; }
+void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att_split_min = min_bin; q4_reset_graphs(); }
 void q4_set_gemv_early(int kind, int slots) { if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots; }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 
@@ -647,13 +649,18 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     const float alpha = (float)(1.0 / sqrt((double)head_size));                     // llama2_q4.cu:273
     dim3 block(ATT_NW * 64);
     // long context: one block per (head, 256-position chunk) + a combine kernel (see attention_split_kernel)
-    const int nsp = divUp(max_seq_len, ATT_CHUNK);
-    const bool split = max_seq_len >= 1024 && scratch != nullptr && head_size == 128 &&
+    const int chunk = g_att_chunk == 128 ? 128 : 256;
+    const int nsp = divUp(max_seq_len, chunk);
+    const bool split = max_seq_len >= g_att_split_min && scratch != nullptr && head_size == 128 &&
                        (size_t)num_heads * nsp * (head_size + 2) * sizeof(float) <= scratch_bytes;
     if (split) {
         const size_t smem = (size_t)(32 + ATT_NW * head_size) * 4;
-        Q4_LAUNCH((attention_split_kernel<16>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
-                  head_size, kv_mul, kv_dim, pPos, alpha);
+        if (chunk == 128)
+            Q4_LAUNCH((attention_split_kernel<16, 2>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
+                      head_size, kv_mul, kv_dim, pPos, alpha);
+        else
+            Q4_LAUNCH((attention_split_kernel<16, 4>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
+                      head_size, kv_mul, kv_dim, pPos, alpha);
         Q4_LAUNCH(attention_combine_kernel, dim3(num_heads), dim3(128), 0, output, (const float*)scratch, head_size, nsp);
         Q4_LAUNCH_CHECK();
         return Q4_OK;
@@ -673,7 +680,13 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     switch (head_size) {
         case 32: Q4_ATT(4) break;
         case 64: Q4_ATT(8) break;
-        case 128: Q4_ATT(16) break;
+        case 128:
+            if (max_seq_len <= 128) {   // first bin: 8 waves cover the 128 positions in one pass (no clamped duplicate loads,
+                                        // cheaper barriers): 7B -n 256 +1 % over the 16-wave block
+                Q4_LAUNCH((attention_kernel<16, 4, 8>), grid, dim3(8 * 64), smem, output, q, key_cache, value_cache, head_size,
+                          kv_mul, kv_dim, pPos, alpha, max_seq_len, g_dbg);
+            } else Q4_ATT(16)
+            break;
         case 256: Q4_ATT(32) break;
         default: return Q4_ERR_UNSUPPORTED_SIZE;
     }
