@@ -601,11 +601,6 @@ int q4_get_logits_array(const Transformer* t, int num_pos, float* host_out) {
     return Q4_OK;
 }
 
-static long time_in_ms() {                                                         // llama2_q4.cu:400-405
-    struct timespec time;
-    timespec_get(&time, TIME_UTC);
-    return time.tv_sec * 1000 + time.tv_nsec / 1000000;
-}
 
 // generate() llama2_q4.cu:436-492 on token ids (no tokenizer, no printing): same loop order -- synchronise,
 // launch step `pos`, then look at the token produced by the PREVIOUS step; same throughput rule (pos-1)/elapsed.
@@ -639,7 +634,6 @@ double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_token
     }
     if (timed_tokens_out) *timed_tokens_out = timed_tokens;
     if (seconds_out) *seconds_out = secs;
-    (void)time_in_ms;
     return secs > 0 ? timed_tokens / secs : 0.0;
 }
 
