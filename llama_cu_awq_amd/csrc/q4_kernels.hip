@@ -162,9 +162,12 @@ __global__ void __launch_bounds__(NW * 64) attention_kernel(q4_half* output, con
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int t = wave * R + row + u * stride;
-        const int tc = t < size ? t : size - 1;
-        kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
-        vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+        kv0[u] = (u32x4){0u, 0u, 0u, 0u};
+        vv0[u] = (u32x4){0u, 0u, 0u, 0u};
+        if (t < size) {                                      // rows past the position are not requested at all
+            kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)t * kv_dim);
+            vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)t * kv_dim);
+        }
     }
     const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
 
