@@ -31,6 +31,10 @@
 #include "q4_device.h"
 #include "q4_internal.h"
 
+#ifndef Q4_W_AUX
+#define Q4_W_AUX 2   // buffer-load cache policy of the weight stream: nt (read once per token)
+#endif
+
 namespace q4 {
 
 constexpr int MODE_PLAIN = 0, MODE_QKV = 1, MODE_FFN = 2;
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             if (ABL == 2)                                                                                         \
                 W[m][s][c] = (u32x4){jj * 2654435761u, jj ^ 0x9E3779B9u, (unsigned)colc[c] * 40503u, jj + 7u};    \
             else                                                                                                  \
-                W[m][s][c] = __builtin_amdgcn_raw_buffer_load_b128(rw[m], jj * 16, colc[c] * a.pw4 * 16, 2);      \
+                W[m][s][c] = __builtin_amdgcn_raw_buffer_load_b128(rw[m], jj * 16, colc[c] * a.pw4 * 16, Q4_W_AUX); \
         }                                                                                                         \
     }
 #pragma unroll
