@@ -31,6 +31,9 @@
 #include "q4_device.h"
 #include "q4_internal.h"
 
+#ifndef Q4_ZS_AUX
+#define Q4_ZS_AUX 0  // zeros / scales: lines are shared by neighbouring lanes and waves, default policy
+#endif
 #ifndef Q4_W_AUX
 #define Q4_W_AUX 2   // buffer-load cache policy of the weight stream: nt (read once per token)
 #endif
@@ -209,8 +212,8 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
         const unsigned j = (sbase + (s)) * 64 + lane;                                                             \
         const unsigned jj = j < (unsigned)a.pw4 ? j : (unsigned)a.pw4 - 1; /* tail lanes re-read the last unit */ \
         _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c++) {       \
-            ZW[m][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4, colc[c] * a.pzh * 4, 0);     \
-            SC[m][s][c] = __builtin_amdgcn_raw_buffer_load_b16(rs[m], (jj >> 2) * 2, colc[c] * a.sh * 2, 0);      \
+            ZW[m][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4, colc[c] * a.pzh * 4, Q4_ZS_AUX); \
+            SC[m][s][c] = __builtin_amdgcn_raw_buffer_load_b16(rs[m], (jj >> 2) * 2, colc[c] * a.sh * 2, Q4_ZS_AUX);  \
             if (ABL == 2)                                                                                         \
                 W[m][s][c] = (u32x4){jj * 2654435761u, jj ^ 0x9E3779B9u, (unsigned)colc[c] * 40503u, jj + 7u};    \
             else                                                                                                  \
