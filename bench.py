@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--ntok", type=int, default=256, help="the CLI's -n")
     ap.add_argument("--model-dir", default=os.environ.get("Q4_MODEL_DIR", "/tmp"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=32, help="decode steps of the CPU restatement timed for cpu_baseline (~0.4 s each at 7B on 16 cores)")
     ap.add_argument("--f64-steps", type=int, default=10, help="positions of the unrounded double forward used as parity yardstick")
     ap.add_argument("--force-dist", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
