@@ -11,6 +11,8 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves) {
         if (g_ablate == 3) return launch_one<MODE_FFN, 2, 2, true, 3>(a, waves);
         if (g_ablate == 4) return launch_one<MODE_FFN, 2, 2, true, 4>(a, waves);
     }
+    if (slots == 3 && a.nslots == 3 && cols == 2 && half_tail(a))
+        return a.rms_w ? launch_one<MODE_FFN, 3, 2, true, 0, 1, true>(a, waves) : launch_one<MODE_FFN, 3, 2, false, 0, 1, true>(a, waves);
     if (cols != 2 && cols != 4) cols = 2;
     if (slots >= 4 && cols == 4) cols = 2;   // gate+up doubles the loads in flight
     Q4_CASE(2, 2) Q4_CASE(2, 4)

@@ -11,6 +11,10 @@ int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
 #undef Q4_KS
         return Q4_ERR_UNSUPPORTED_SIZE;
     }
+    if (cols == 4 && slots == 3 && a.nslots == 3 && half_tail(a)) {   // K = 5120 (13B o-proj and unfused q/k/v): shared half slot
+        if (divUp(a.N, 4 * waves) <= 320) return launch_one<MODE_PLAIN, 3, 4, false, 5, 1, true>(a, waves);
+        return launch_one<MODE_PLAIN, 3, 4, false, 0, 1, true>(a, waves);
+    }
     if (cols == 4 && slots <= 3 && divUp(a.N, 4 * waves) <= 320) {   // about one block per CU: every load first
         if (slots == 2) return launch_one<MODE_PLAIN, 2, 4, false, 5>(a, waves);
         if (slots == 3) return launch_one<MODE_PLAIN, 3, 4, false, 5>(a, waves);

@@ -117,8 +117,12 @@ struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT
 // totals meet in LDS. The N = dim projections (o, down) have only N/4 = 1024 column groups = one wave per SIMD, and a
 // single wave issues one VALU instruction per ~5.5 cycles (measured) -- the ~1000-instruction down-projection wave
 // was a 3.4 us serial chain; splitting K doubles the waves and halves that chain.
-template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1>
+// HALF: the column's last k-slot holds at most 32 uint4 (K = 5120: 160 = 2 x 64 + 32). Instead of running that slot with
+// half of the lanes multiplying zero padding, lanes 0-31 take it for column c and lanes 32-63 for column c + 1 of each
+// column pair: one load and one dequant-dot evaluation per PAIR (13B q/k/v/o/gate/up: 12 -> 10 per wave).
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
 __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
+    static_assert(!HALF || (KS == 1 && COLS % 2 == 0), "shared half slot: no K split, column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
     static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
@@ -220,8 +224,23 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
                 W[m][s][c] = __builtin_amdgcn_raw_buffer_load_b128(rw[m], jj * 16, colc[c] * a.pw4 * 16, Q4_W_AUX); \
         }                                                                                                         \
     }
+    // the shared half slot: column offset per lane (lanes 32-63 belong to the pair's second column), results kept in
+    // the pair's first entries W/ZW/SC[m][SLOTS-1][2p]
+    const bool upper = lane >= 32u;
+#define Q4_ISSUE_HALF()                                                                                           \
+    {                                                                                                             \
+        const unsigned jh = (SLOTS - 1) * 64 + (lane & 31u);                                                      \
+        const unsigned jj = jh < (unsigned)a.pw4 ? jh : (unsigned)a.pw4 - 1;                                      \
+        _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c += 2) {    \
+            const unsigned cw = upper ? (unsigned)colc[c + 1] : (unsigned)colc[c];                                \
+            ZW[m][SLOTS - 1][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4 + cw * a.pzh * 4, 0, 0); \
+            SC[m][SLOTS - 1][c] = __builtin_amdgcn_raw_buffer_load_b16(rs[m], (jj >> 2) * 2 + cw * a.sh * 2, 0, 0);  \
+            W[m][SLOTS - 1][c] = __builtin_amdgcn_raw_buffer_load_b128(rw[m], jj * 16 + cw * a.pw4 * 16, 0, 2);   \
+        }                                                                                                         \
+    }
+#define Q4_ISSUE_ANY(s) { if (HALF && (s) == SLOTS - 1) Q4_ISSUE_HALF() else Q4_ISSUE_SLOT(s) }
 #pragma unroll
-    for (int s = 0; s < PRE; s++) Q4_ISSUE_SLOT(s)
+    for (int s = 0; s < PRE; s++) Q4_ISSUE_ANY(s)
     __builtin_amdgcn_sched_barrier(0);
 
     if (ABL == 3) ts[1] = __builtin_readcyclecounter();
@@ -274,9 +293,11 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     if (ABL != 4 && !early) stage_tail();      // (ABL 4: no staging at all, garbage x -- the kernel without the x chain)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = PRE; s < SLOTS; s++) Q4_ISSUE_SLOT(s)
+    for (int s = PRE; s < SLOTS; s++) Q4_ISSUE_ANY(s)
     __builtin_amdgcn_sched_barrier(0);
     if (ABL != 4 && early) stage_tail();
+#undef Q4_ISSUE_ANY
+#undef Q4_ISSUE_HALF
 #undef Q4_ISSUE_SLOT
 
 
@@ -289,16 +310,18 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) {
+        const bool hs = HALF && s == SLOTS - 1;                 // shared half slot: both halves of the wave read units 0-31
+        const unsigned lu = hs ? (lane & 31u) : lane;
         u32x4 X[4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[d] = xs[(((sbase + s) * 4 + d) << 6) + lane];
-        const float corr = sx[(sbase + s) * 64 + lane];
-        const unsigned j = (sbase + s) * 64 + lane;
+        for (int d = 0; d < 4; d++) X[d] = xs[(((sbase + s) * 4 + d) << 6) + lu];
+        const float corr = sx[(sbase + s) * 64 + lu];
+        const unsigned j = (sbase + s) * 64 + lu;
         const unsigned zsh = ((j >> 2) & 7u) * 4u;
 #pragma unroll
         for (int m = 0; m < NMAT; m++)
 #pragma unroll
-            for (int c = 0; c < COLS; c++) {
+            for (int c = 0; c < COLS; c += (hs ? 2 : 1)) {
                 float t;
                 if (ABL == 1) {
                     const u32x4 w = W[m][s][c];
@@ -320,7 +343,13 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
                     t = __builtin_fmaf(zf, corr, t);                 // - z * 2^-20 * sum x
                 }
                 // idle tail lanes (j >= pw4) multiply re-read weights by the zero padding of xs/sx: exactly 0
-                colsum[m][c] = __builtin_fmaf(h2f(SC[m][s][c]), t, colsum[m][c]);
+                if (hs) {                                       // lanes 0-31 worked for column c, lanes 32-63 for column c + 1
+                    const float v = h2f(SC[m][s][c]) * t;
+                    colsum[m][c] += upper ? 0.f : v;
+                    colsum[m][c + 1] += upper ? v : 0.f;
+                } else {
+                    colsum[m][c] = __builtin_fmaf(h2f(SC[m][s][c]), t, colsum[m][c]);
+                }
             }
         if (ABL == 3 && s < 3) { asm volatile("" : "+v"(colsum[0][0])); ts[4 + s] = __builtin_readcyclecounter(); }
     }
@@ -419,8 +448,9 @@ static inline int cu_count() {
 
 // host-side dispatch -------------------------------------------------------------------------------
 extern int g_ablate;
+extern int g_half_tail; // 1: shared half slot where the shape allows it (13B: K = 5120)
 extern int g_ksplit;    // 1: split K over two waves for the plain GEMV (default), 0: one wave per column group
-template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1>
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
 static int launch_one(const GemvArgs& a0, int waves) {
     if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS / 64;
     const int cols_per_block = COLS * (waves / KS);
@@ -437,15 +467,18 @@ static int launch_one(const GemvArgs& a0, int waves) {
     if (smem > 64 * 1024) {   // long-K split kernels stage up to 32768 inputs: opt in to the CU's 160 KB once
         static bool opted = false;
         if (!opted) {
-            Q4_HIP(hipFuncSetAttribute((const void*)gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>,
+            Q4_HIP(hipFuncSetAttribute((const void*)gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS, HALF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             opted = true;
         }
     }
-    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS>), grid, dim3(waves * 64), smem, a);
+    Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS, HALF>), grid, dim3(waves * 64), smem, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
+
+// the last k-slot of a column holds at most 32 uint4: candidates for the shared half slot (K = 5120, 11008, ...)
+static inline bool half_tail(const GemvArgs& a) { return g_half_tail && a.pw4 - (a.nslots - 1) * 64 <= 32; }
 
 // smallest instantiated SLOTS covering nslots (K <= 16384), 0 if none
 static inline int pick_slots(int nslots) {

@@ -15,6 +15,7 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
 int g_ablate = 0;
 int g_ksplit = 1;
+int g_half_tail = 1;
 int g_att_chunk = 256;       // positions per split-attention block (128 or 256)
 int g_att_split_min = 1024;  // smallest sequence-length bin that uses the split-context kernels
 unsigned long long* g_dbg = nullptr;
@@ -570,6 +571,7 @@ extern "C" {
 
 void q4_set_ablate(int mode) { g_ablate = mode; }
 void q4_set_ksplit(int on) { g_ksplit = on; }
+void q4_set_half_tail(int on) { g_half_tail = on; q4_reset_graphs(); }
 void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att_split_min = min_bin; q4_reset_graphs(); }
 void q4_set_gemv_early(int kind, int slots) { if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots; }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
