@@ -39,8 +39,11 @@ __device__ __forceinline__ float block_tree_max(float v, float* red) {
 }
 
 // softmax_logits_kernel gpu_kernels.h:499-550, in place on `logits`, indices[t] = t (:507)
-__device__ void softmax_phase(q4_half* __restrict__ logits, int size, float temperature, int* __restrict__ indices, float* red) {
+// Returns (register path) the largest probability and its lowest index packed as prob_bits << 16 | (0xFFFF - index)
+// -- the first entry of the descending stable sort -- or 0 (memory path).
+__device__ unsigned softmax_phase(q4_half* __restrict__ logits, int size, float temperature, int* __restrict__ indices, float* red) {
     const int tid = threadIdx.x;
+    unsigned top = 0;
     if (size <= SMP_T * SMP_E) {
         float v[SMP_E];
 #pragma unroll
@@ -67,8 +70,24 @@ __device__ void softmax_phase(q4_half* __restrict__ logits, int size, float temp
 #pragma unroll
         for (int k = 0; k < SMP_E; k++) {
             const int t = tid + k * SMP_T;
-            if (t < size) { logits[t] = f2h(v[k] / sum); indices[t] = t; }   // :549
+            if (t < size) {
+                const uint16_t pb = f2h(v[k] / sum);                                 // :549
+                logits[t] = pb;
+                indices[t] = t;
+                const unsigned key = ((unsigned)pb << 16) | (0xFFFFu - (unsigned)t);
+                top = key > top ? key : top;
+            }
         }
+        // block maximum of the packed keys (probabilities are non-negative: the bit pattern orders them)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(top, off); top = o > top ? o : top; }
+        unsigned* redu = reinterpret_cast<unsigned*>(red);
+        __syncthreads();
+        if ((tid & 63) == 0) redu[tid >> 6] = top;
+        __syncthreads();
+        top = redu[0];
+#pragma unroll
+        for (int w = 1; w < SMP_W; w++) top = redu[w] > top ? redu[w] : top;
     } else {   // larger vocabularies: the same arithmetic through memory
         for (int t = tid; t < size; t += SMP_T) {
             indices[t] = t;
@@ -90,6 +109,7 @@ __device__ void softmax_phase(q4_half* __restrict__ logits, int size, float temp
         for (int t = tid; t < size; t += SMP_T) logits[t] = f2h(h2f(logits[t]) / sum);
     }
     __syncthreads();
+    return top;
 }
 
 // lanes of this wave (among `valid` ones) holding the same 8-bit digit
@@ -271,10 +291,14 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
     unsigned* cnt = onchip ? dyn + SMP_T * SMP_E : dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) hit = 0x7fffffff;
-    softmax_phase(logits, n, temperature, indices, red);                         // sampler.h:53
+    const unsigned top = softmax_phase(logits, n, temperature, indices, red);    // sampler.h:53
     const int E = (n + SMP_T - 1) / SMP_T;
     int token = 0;
-    if (!do_sort) {                                                              // sampler.h:57-59
+    if (do_sort && top != 0 && h2f((uint16_t)(top >> 16)) >= threshold) {
+        // the first sorted entry (largest probability, lowest index among equals) already reaches the threshold: its
+        // prefix IS that probability, so it is the sample -- no sort, no scan (the usual case at low temperature)
+        token = (int)(0xFFFFu - (top & 0xFFFFu));
+    } else if (!do_sort) {                                                              // sampler.h:57-59
         const uint16_t* keys = logits;
         scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
         if (tid == 0) token = hit == 0x7fffffff ? n - 1 : hit;                   // indices[t] == t

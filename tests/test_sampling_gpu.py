@@ -17,7 +17,8 @@ def model(tmp_path_factory):
     return p
 
 
-@pytest.mark.parametrize("temperature,topp", [(0.5, 0.6), (1.0, 0.9), (0.8, 1.0), (1.3, 0.0), (0.3, 0.95)])
+@pytest.mark.parametrize("temperature,topp", [(0.5, 0.6), (1.0, 0.9), (0.8, 1.0), (1.3, 0.0), (0.3, 0.95),
+                                              (0.05, 0.9), (0.12, 0.6)])   # peaked: the top entry alone reaches the threshold
 def test_sample_matches_restatement(q4, orc, model, temperature, topp):
     L = q4.lib()
     t = q4.Transformer(model, temperature=temperature, topp=topp, seed=1234)
