@@ -10,6 +10,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libllama2_q4.so")
+# the -DQ4_PROFILING build of the same sources (ablations, launch-skip mask, tuning setters): tools/ and
+# tests/prof_cases.py select it with Q4_PROFILING_BUILD=1 or use_profiling_build() before the first lib() call
+PROF_LIB_PATH = os.path.join(_HERE, "libllama2_q4_prof.so")
 
 MAX_SEQ_LEN = 128 * 1024
 
@@ -63,17 +66,25 @@ SYMBOLS = [
 ]
 
 _lib = None
+_use_prof = os.environ.get("Q4_PROFILING_BUILD", "") == "1"
+
+
+def use_profiling_build():
+    global _use_prof
+    assert _lib is None, "select the profiling build before the library is loaded"
+    _use_prof = True
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = PROF_LIB_PATH if _use_prof else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            "libllama2_q4.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
-            "`make -C llama_cu_awq_amd/csrc`. There is no CPU fallback for this path." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "%s is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C llama_cu_awq_amd/csrc`. There is no CPU fallback for this path." % (os.path.basename(path), path))
+    L = C.CDLL(path)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     L.q4_status_string.restype = C.c_char_p
     L.q4_status_string.argtypes = [i]
@@ -161,8 +172,12 @@ def lib():
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i)]
     L.q4_bench_in_network.restype = C.c_double
     L.q4_device_info.argtypes = [C.c_char_p, i, C.POINTER(i), C.POINTER(C.c_size_t)]
-    L.q4_set_gemv_tune.argtypes = [i, i, i]
-    L.q4_set_gemv_tune.restype = None
+    if _use_prof:
+        for name, at in (("q4_set_gemv_tune", [i, i, i]), ("q4_set_gemv_early", [i, i]), ("q4_set_half_tail", [i]),
+                         ("q4_set_ksplit", [i]), ("q4_set_ablate", [i]), ("q4_set_skip_mask", [i]),
+                         ("q4_set_attention_split", [i, i]), ("q4_set_debug_buffer", [vp])):
+            getattr(L, name).argtypes = at
+            getattr(L, name).restype = None
     _lib = L
     return L
 
@@ -340,6 +355,8 @@ class Transformer:
     def generate_ids(self, prompt_tokens, steps):
         """generate() on token ids: returns (tokens ring [pos+1], tok/s, timed_tokens, seconds)."""
         t = np.ascontiguousarray(prompt_tokens, dtype=np.int32)
+        if steps <= 0 or steps > self.config.seq_len:          # the C side clamps the same way (llama2_q4.cu:690)
+            steps = self.config.seq_len
         out = np.zeros(steps + 2, dtype=np.int32)
         timed = C.c_int()
         secs = C.c_double()

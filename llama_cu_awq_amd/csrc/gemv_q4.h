@@ -58,7 +58,7 @@ struct GemvArgs {
     int N_kv;               // QKV with grouped-query attention: columns of the k and v matrices (0: same as N)
     int pw4, pzh, sh, nslots;
     int accum;              // PLAIN: out = half(float(out) + sum)
-    int loff;               // PLAIN: -1 = none. QKV: KV-cache layer offset
+    long long loff;         // PLAIN: -1 = none. QKV: KV-cache layer offset (64-bit: 13B at 16K positions exceeds 2^31 halves)
     int rope;               // QKV: rotate q and k in the epilogue
     int head_size;
     float rope_theta;

@@ -62,9 +62,10 @@ struct GemvTune { int cols; int waves; int early; };   // columns per wave, wave
 
 // fused layer kernels (validated against the unfused chain in tests/test_fusion_gpu.py)
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w,
-                     const QWeight* qw, const QWeight* kw, const QWeight* vw, int dim, int kv_dim, int loff,
-                     const int* pPos, int head_size, float rope_theta);
-int rope_table_build(int seq_len, int head_size, float theta);   // (cos,sin) table for the fused QKV epilogue
+                     const QWeight* qw, const QWeight* kw, const QWeight* vw, int dim, int kv_dim, long long loff,
+                     const int* pPos, int head_size, float rope_theta, const float2* rope_table);
+const float2* rope_table_of(const RunState* s);   // this model's table (q4_runtime.hip), null if none
+int rope_table_build(float2** out, int seq_len, int head_size, float theta);   // (cos,sin) table for the fused QKV epilogue
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                      int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
                      size_t scratch_bytes);

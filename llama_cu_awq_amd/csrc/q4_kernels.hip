@@ -488,36 +488,22 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
 __global__ void rope_table_kernel(float2* table, int seq_len, int head_size, float rope_theta) {
     const int hp = head_size >> 1;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= seq_len * hp) return;
+    if ((size_t)blockIdx.x * blockDim.x + threadIdx.x >= (size_t)seq_len * hp) return;
     float c, s;
     rope_angle(idx % hp, head_size, idx / hp, rope_theta, c, s);
     table[idx] = make_float2(c, s);
 }
 
-struct RopeTable { float2* ptr; int seq_len; int head_size; float theta; };
-static RopeTable g_rope_tables[4] = {};
-
-const float2* rope_table_lookup(int head_size, float theta) {
-    for (auto& t : g_rope_tables)
-        if (t.ptr && t.head_size == head_size && t.theta == theta) return t.ptr;
-    return nullptr;
-}
-int rope_table_build(int seq_len, int head_size, float theta) {
-    for (auto& t : g_rope_tables)
-        if (t.ptr && t.head_size == head_size && t.theta == theta && t.seq_len >= seq_len) return Q4_OK;
-    for (auto& t : g_rope_tables)
-        if (!t.ptr || (t.head_size == head_size && t.theta == theta)) {
-            if (t.ptr) hipFree(t.ptr);
-            t.ptr = nullptr;
-            Q4_HIP(hipMalloc((void**)&t.ptr, (size_t)seq_len * (head_size / 2) * sizeof(float2)));
-            t.seq_len = seq_len; t.head_size = head_size; t.theta = theta;
-            const int n = seq_len * (head_size / 2);
-            Q4_LAUNCH(rope_table_kernel, dim3(divUp(n, 256)), dim3(256), 0, t.ptr, seq_len, head_size, theta);
-            Q4_LAUNCH_CHECK();
-            Q4_HIP(hipStreamSynchronize(g_stream));
-            return Q4_OK;
-        }
-    return Q4_OK;   // no free slot: the kernels fall back to computing the angles
+// One table per Transformer (owned by its slabs in q4_runtime.hip, freed with it): seq_len rows of head_size/2 pairs.
+int rope_table_build(float2** out, int seq_len, int head_size, float theta) {
+    *out = nullptr;
+    const size_t n = (size_t)seq_len * (head_size / 2);
+    if (n == 0 || n > (1u << 30)) return Q4_OK;   // no table: the kernels compute the angles
+    if (hipMalloc((void**)out, n * sizeof(float2)) != hipSuccess) { *out = nullptr; (void)hipGetLastError(); return Q4_OK; }
+    Q4_LAUNCH(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, *out, seq_len, head_size, theta);
+    Q4_LAUNCH_CHECK();
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    return Q4_OK;
 }
 
 // ---- fused-path launchers used by the network -----------------------------------------------------
@@ -533,8 +519,8 @@ static int fill_geom(GemvArgs& a, int K, int N) {
 }
 
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w, const QWeight* qw,
-                     const QWeight* kw, const QWeight* vw, int dim, int kv_dim, int loff, const int* pPos,
-                     int head_size, float rope_theta) {
+                     const QWeight* kw, const QWeight* vw, int dim, int kv_dim, long long loff, const int* pPos,
+                     int head_size, float rope_theta, const float2* rope_table) {
     if (kv_dim > dim || (kv_dim & 7)) return Q4_ERR_ARG;
     GemvArgs a = {};
     int rc = fill_geom(a, dim, dim);
@@ -544,7 +530,7 @@ int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, con
     a.out[0] = q; a.out[1] = kc; a.out[2] = vc;
     a.x = x; a.rms_w = rms_w; a.pPos = pPos; a.loff = loff;
     a.rope = head_size > 0; a.head_size = head_size > 0 ? head_size : 2; a.rope_theta = rope_theta;
-    a.rope_table = head_size > 0 ? rope_table_lookup(head_size, rope_theta) : nullptr;
+    a.rope_table = head_size > 0 ? rope_table : nullptr;   // [seq_len][head_size/2] for THIS model, or null: compute
     a.early = g_tune[TUNE_QKV].early;
     return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
 }
@@ -569,16 +555,19 @@ using namespace q4;
 // =================================================================================================
 extern "C" {
 
+#ifdef Q4_PROFILING
+// Measurement knobs of the profiling build (libllama2_q4_prof.so, used by tools/ and tests/prof_cases.py only): the
+// shipped libllama2_q4.so exports exactly what include/llama2_q4.h declares.
 void q4_set_ablate(int mode) { g_ablate = mode; }
 void q4_set_ksplit(int on) { g_ksplit = on; }
 void q4_set_half_tail(int on) { g_half_tail = on; q4_reset_graphs(); }
 void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att_split_min = min_bin; q4_reset_graphs(); }
 void q4_set_gemv_early(int kind, int slots) { if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots; }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
-
 void q4_set_gemv_tune(int kind, int cols, int waves) {
     if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }
 }
+#endif
 
 int q4_rmsnorm(q4_half* o, const q4_half* x, const q4_half* weight, int size) {
     if (size & 7) return Q4_ERR_UNSUPPORTED_SIZE;
@@ -678,9 +667,12 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     dim3 grid(num_heads);
 #define Q4_ATT(L)                                                                                                  \
     {                                                                                                              \
-        if (smem > 64 * 1024)                                                                                      \
+        static size_t opted = 64 * 1024;   /* per instantiation: opt in to more LDS only when a launch needs more */ \
+        if (smem > opted) {                                                                                        \
             Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                \
+            opted = smem;                                                                                          \
+        }                                                                                                          \
         Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache, head_size, kv_mul,  \
                   kv_dim, pPos, alpha, max_seq_len, g_dbg);                                                        \
     }
@@ -729,7 +721,7 @@ int q4_convert_fp16_to_fp32(float* out, const q4_half* in, int elements) {
 }
 
 // logits -> logits_array[*pPos] (llama2_q4.cu:377-382), position read on the device so it can be graph-captured
-int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos) {
+__attribute__((visibility("hidden"))) int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos) {
     Q4_LAUNCH(convert_fp16_to_fp32_kernel, dim3(divUp(vocab_size, 256)), dim3(256), 0, logits_array,
                        logits, vocab_size, pPos, vocab_size);
     Q4_LAUNCH_CHECK();

@@ -33,8 +33,15 @@ struct Slabs {
     void* state = nullptr;
     void* shared = nullptr;
     void* logits_array = nullptr;
+    float2* rope_table = nullptr;   // [seq_len][head_size/2] (cos, sin), lives exactly as long as the Transformer
 };
 static std::map<const Transformer*, Slabs> g_slabs;
+// the network entry points take (Config, RunState, TransformerWeights), not the Transformer: tables are found by RunState
+static std::map<const RunState*, const float2*> g_rope_by_state;
+const float2* rope_table_of(const RunState* s) {
+    auto it = g_rope_by_state.find(s);
+    return it == g_rope_by_state.end() ? nullptr : it->second;
+}
 
 // graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
 static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][8];
@@ -58,7 +65,7 @@ size_t qweight_bytes(int height, int width, size_t* wb, size_t* zb, size_t* sb) 
 
 using namespace q4;
 
-extern "C" int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos);
+extern "C" __attribute__((visibility("hidden"))) int q4_copy_logits_at_pos(float* logits_array, const q4_half* logits, int vocab_size, const int* pPos);
 
 extern "C" {
 
@@ -275,7 +282,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         s->value_cache = (q4_half*)c.take(sizeof(q4_half) * p->n_layers * p->seq_len * kv_dim);
         s->pos = (int*)c.take(sizeof(int));
     }
-    if (!rc && hipHostMalloc(&slabs.shared, sizeof(SharedData), hipHostMallocMapped) != hipSuccess) {   // cudaMallocHost :50
+    if (!rc && hipHostMalloc(&slabs.shared, sizeof(SharedData), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {   // cudaMallocHost :50
         printf("malloc failed for allocaing run state!\n");
         rc = Q4_ERR_ALLOC;
     }
@@ -299,14 +306,17 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         memset(t, 0, sizeof(*t));
         return rc;
     }
+    // fused QKV + RoPE epilogue (multi-head and grouped-query models alike): table of this model's own seq_len
+    rc = rope_table_build(&slabs.rope_table, p->seq_len, p->dim / p->n_heads, p->rope_theta);
     g_slabs[t] = slabs;
-    if (p->dim == kv_dim) rope_table_build(p->seq_len, p->dim / p->n_heads, p->rope_theta);   // fused QKV+RoPE path only
+    if (rc) { q4_free_transformer(t); return rc; }
+    if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
     return Q4_OK;
 }
 
 void q4_free_transformer(Transformer* t) {                                        // :428-432
     if (!t) return;
-    if (g_graph_owner == t) q4_reset_graphs();
+    if (g_graph_owner == (const void*)&t->state) q4_reset_graphs();   // the owner is recorded as the RunState (run_transformer_at)
     auto it = g_slabs.find(t);
     if (it != g_slabs.end()) {
         hipDeviceSynchronize();
@@ -314,6 +324,8 @@ void q4_free_transformer(Transformer* t) {                                      
         if (it->second.state) hipFree(it->second.state);
         if (it->second.shared) hipHostFree(it->second.shared);
         if (it->second.logits_array) hipFree(it->second.logits_array);
+        if (it->second.rope_table) hipFree(it->second.rope_table);
+        g_rope_by_state.erase(&t->state);
         g_slabs.erase(it);
     }
     free(t->weights.layers);
@@ -343,8 +355,12 @@ TransformerWeights* q4_transformer_weights(Transformer* t) { return &t->weights;
 
 // measurement knob (tools/breakdown.py): leave out a class of launches to read its marginal cost inside the token
 // graph. Results are garbage with any bit set; never set by the product path.
+#ifdef Q4_PROFILING
 static int g_skip = 0;
 void q4_set_skip_mask(int mask) { g_skip = mask; q4_reset_graphs(); }
+#else
+enum { g_skip = 0 };   // the shipped library cannot leave launches out
+#endif
 // in-network timing (q4_bench_in_network): launches of the class whose bit is in g_time_mask carry dispatch timestamps
 static int g_time_mask = 0;
 static std::vector<hipEvent_t>* g_time_events = nullptr;
@@ -369,26 +385,29 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     const int head_size = dim / p->n_heads;
     const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
     const int kv_mul = p->n_heads / p->n_kv_heads;
+    const float2* rope_table = rope_table_of(s);
 
     Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
-        const int loff = l * p->seq_len * kv_dim;                                                      // :303
+        // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
+        // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
+        const long long loff = (long long)l * p->seq_len * kv_dim;
         if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
-                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta));
+                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table));
         } else {
             Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_att_weight, dim));                                      // :300
             if (dim == kv_dim) {
-                Q4_TRY(q4_qkv_matvec(s->q, s->key_cache, s->value_cache, s->xb, &L->wq_q, &L->wq_k, &L->wq_v, dim, dim, loff, pPos));
+                Q4_TRY(q4_qkv_matvec(s->q, s->key_cache + loff, s->value_cache + loff, s->xb, &L->wq_q, &L->wq_k, &L->wq_v, dim, dim, 0, pPos));
             } else {
                 Q4_TRY(q4_matmul_q4(s->q, s->xb, &L->wq_q, dim, dim, 0, -1, nullptr));                 // :310-312
-                Q4_TRY(q4_matmul_q4(s->key_cache, s->xb, &L->wq_k, dim, kv_dim, 0, loff, pPos));
-                Q4_TRY(q4_matmul_q4(s->value_cache, s->xb, &L->wq_v, dim, kv_dim, 0, loff, pPos));
+                Q4_TRY(q4_matmul_q4(s->key_cache + loff, s->xb, &L->wq_k, dim, kv_dim, 0, 0, pPos));
+                Q4_TRY(q4_matmul_q4(s->value_cache + loff, s->xb, &L->wq_v, dim, kv_dim, 0, 0, pPos));
             }
-            Q4_TRY(q4_rope_rotation(s->q, s->key_cache, p->n_heads, p->n_kv_heads, head_size, pPos, loff, p->rope_theta));   // :317
+            Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
         Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
                                       seq_len_bin, pPos, (float*)s->att,
@@ -488,7 +507,7 @@ void q4_sampler_delete(Sampler* s) {
     free(s);
 }
 
-int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin);   // q4_sampling.hip
+__attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin);   // q4_sampling.hip
 
 static bool sampler_is_greedy(const Sampler* sampler, int gen_token) {
     return sampler->temperature == 0.0f || !gen_token;                             // sampler.h:47

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
 
 }  // namespace
 
-extern "C" int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin) {
+extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin) {
     const int n = sampler->vocab_size;
     const int do_sort = !(sampler->topp <= 0 || sampler->topp >= 1);
     const float threshold = do_sort ? coin * sampler->topp : coin;                   // sampler.h:57-59,69

@@ -28,6 +28,32 @@ def test_library_exports_every_declared_symbol():
     missing = sorted(declared - exported)
     assert not missing, "declared in llama2_q4.h but not exported: %s" % missing
     assert set(api.SYMBOLS) <= exported
+    # and nothing else: measurement knobs live in the -DQ4_PROFILING build (libllama2_q4_prof.so) only
+    extra = sorted(exported - declared)
+    assert not extra, "exported by libllama2_q4.so but not declared in llama2_q4.h: %s" % extra
+
+
+def test_profiling_build_adds_only_the_measurement_knobs():
+    from llama_cu_awq_amd import api
+    declared = _declared_functions()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.PROF_LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert declared <= exported
+    assert all(n.startswith("q4_set_") for n in exported - declared), sorted(exported - declared)
+
+
+def test_cpp_wrappers_compile_and_link_against_the_library(tmp_path):
+    """include/llama2_q4.hpp (the reference's own host-function names over the C ABI) is consumed by a real C++
+    translation unit: tests/consumer/hpp_consumer.cpp compiles with g++ and links against libllama2_q4.so."""
+    from llama_cu_awq_amd import api
+    exe = str(tmp_path / "hpp_consumer")
+    libdir = os.path.dirname(api.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "consumer", "hpp_consumer.cpp"), "-o", exe,
+                           "-L", libdir, "-lllama2_q4", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    # without arguments it only resolves the symbols and prints the status table (no GPU needed)
+    out = subprocess.check_output([exe]).decode()
+    assert "Unsupported matmul size. Exiting" in out
 
 
 def test_library_loads_without_gpu_and_reports_status_strings():
