@@ -117,12 +117,16 @@ def test_unrounded_f64_forward_brackets_the_restatement(tmp_path):
     m.close()
 
 
-@pytest.mark.parametrize("n,temperature,topp", [(1000, 1.0, 0.9), (32000, 0.5, 0.6), (32000, 1.0, 0.9), (4097, 0.7, 1.0)])
+@pytest.mark.parametrize("n,temperature,topp", [(1000, 1.0, 0.9), (32000, 0.5, 0.6), (32000, 1.0, 0.9), (4097, 0.7, 1.0),
+                                                (32000, 0.2, 0.9), (40000, 1.0, 0.95)])
 def test_topp_restatement_against_plain_numpy(n, temperature, topp):
     """The restated sampler (fp16 rounding points, fixed-order fp16 prefix scan) against the textbook float64 form:
-    sort descending, cumulative sum, first index reaching coin*topp. They may only disagree where the cumulative
-    probability is within fp16 accumulation error of the threshold."""
+    sort descending, cumulative sum, first index reaching coin*topp. They may only disagree inside the fp16 band of
+    the prefix sum: the exact cumulative probability at the restated pick brackets the threshold to within BAND
+    (measured worst 5.7e-4 = half an fp16 ulp near 1; the bound is 3x that), and wherever the threshold is further
+    than BAND from both edges of the textbook pick the two agree exactly."""
     import oracle
+    BAND = 2e-3
     rng = np.random.default_rng(n + int(100 * temperature))
     logits = (3.0 * rng.standard_normal(n)).astype(np.float16)
     x = (logits.astype(np.float32) / np.float32(temperature)).astype(np.float16).astype(np.float64)
@@ -131,13 +135,16 @@ def test_topp_restatement_against_plain_numpy(n, temperature, topp):
     order = np.lexsort((np.arange(n), -p.astype(np.float16).astype(np.float64))) if 0 < topp < 1 else np.arange(n)
     cum = np.cumsum(p[order])
     agree = 0
-    for coin in (0.03, 0.2, 0.41, 0.77, 0.93):
+    coins = np.linspace(0.01, 0.99, 50)
+    for coin in coins:
         thr = coin * topp if 0 < topp < 1 else coin
-        tok = oracle.lib().orc_sample_topp(oracle.f16_bits(logits.copy()), n, temperature, topp, coin)
-        k = int(np.searchsorted(cum, thr, side="left"))
+        tok = oracle.lib().orc_sample_topp(oracle.f16_bits(logits.copy()), n, temperature, topp, float(coin))
+        k = min(int(np.searchsorted(cum, thr, side="left")), n - 1)
         pos = int(np.nonzero(order == tok)[0][0])
-        # fp16 accumulation: the restated prefix at `pos` may be off by ~1e-2 relative from the exact cumulative sum
         lo = cum[pos - 1] if pos > 0 else 0.0
-        assert lo - 2e-2 <= thr <= cum[pos] + 2e-2 or pos == n - 1, (coin, pos, k, lo, cum[pos], thr)
-        agree += pos == min(k, n - 1)
-    assert agree >= 2
+        assert lo - BAND <= thr <= cum[pos] + BAND or pos == n - 1, (coin, pos, k, lo, cum[pos], thr)
+        klo = cum[k - 1] if k > 0 else 0.0
+        if thr - klo > BAND and cum[k] - thr > BAND:
+            assert pos == k, (coin, pos, k)
+        agree += pos == k
+    assert agree >= 0.7 * len(coins), agree

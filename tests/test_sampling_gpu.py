@@ -42,6 +42,67 @@ def test_sample_matches_restatement(q4, orc, model, temperature, topp):
     t.close()
 
 
+@pytest.fixture(scope="module")
+def big_vocab_models(tmp_path_factory):
+    d = tmp_path_factory.mktemp("v")
+    out = {}
+    for name in ("v32k", "v40k"):
+        out[name] = str(d / (name + ".bin"))
+        synth.write_model(out[name], name, seed=5)
+    return out
+
+
+def _logit_case(rng, vocab, trial):
+    """Distributions the sorted-prefix search must get right: ordinary, wide, flat (the fp16 prefix sum saturates),
+    exactly flat, ties at the maximum, ties everywhere (few distinct values), one dominant entry."""
+    kind = trial % 7
+    if kind == 0:
+        x = rng.standard_normal(vocab) * 2.0
+    elif kind == 1:
+        x = rng.standard_normal(vocab) * 6.0
+    elif kind == 2:
+        x = rng.standard_normal(vocab) * 0.05                   # nearly flat: ~1/vocab each
+    elif kind == 3:
+        x = np.full(vocab, float(rng.standard_normal()))         # exactly flat: every key equal
+    elif kind == 4:
+        x = rng.standard_normal(vocab) * 2.0
+        x[rng.integers(0, vocab, 8)] = x.max() + 0.5             # 8-way tie at the top
+    elif kind == 5:
+        x = rng.integers(-3, 4, vocab).astype(np.float64)        # 7 distinct values: long runs of equal keys
+    else:
+        x = rng.standard_normal(vocab)
+        x[int(rng.integers(0, vocab))] = 12.0
+    return x.astype(np.float16)
+
+
+@pytest.mark.parametrize("name", ["v32k", "v40k"])
+@pytest.mark.parametrize("temperature,topp", [(0.5, 0.6), (1.0, 0.9), (0.8, 1.0), (1.3, 0.0), (0.3, 0.95), (0.05, 0.9),
+                                              (0.12, 0.6)])
+def test_sample_matches_restatement_at_production_vocab(q4, orc, big_vocab_models, name, temperature, topp):
+    """sample() sampler.h:51-81 where the CLI runs it: vocab 32000 (32 register-resident keys per thread, packed ranks,
+    transposed LDS layout) and vocab 40000 (> 32768: the same passes through global memory), 105 trials per (T, p)
+    over ordinary / flat / tied distributions, token-exact against the restatement with the same coin stream."""
+    L = q4.lib()
+    t = q4.Transformer(big_vocab_models[name], temperature=temperature, topp=topp, seed=99)
+    vocab = t.config.vocab_size
+    rng = np.random.default_rng(int(temperature * 1000 + topp * 10) + vocab)
+    state = C.c_ulonglong(99)
+    bad = []
+    for trial in range(105):
+        logits = _logit_case(rng, vocab, trial)
+        t.reset([1])
+        q4.check(L.q4_memcpy_h2d(t.state.contents.logits, logits.ctypes.data, logits.nbytes))
+        q4.check(L.q4_sample(t.sampler, t.state, 1))
+        q4.synchronize()
+        coin = L.random_f32(C.byref(state))
+        ref = orc.lib().orc_sample_topp(orc.f16_bits(logits.copy()), vocab, temperature, topp, coin)
+        assert t.pos() == 1
+        if t.token(1) != ref:
+            bad.append((trial, trial % 7, int(t.token(1)), ref, coin))
+    assert not bad, bad[:8]
+    t.close()
+
+
 def test_generate_with_temperature_runs(q4, model):
     """End to end: the CLI default (-t 0.5 -p 0.6) goes through the sampling kernels outside the captured graph."""
     t = q4.Transformer(model, temperature=0.5, topp=0.6, seed=7)
