@@ -210,8 +210,10 @@ int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, 
                           int copyLogits, Sampler* pSampler);
 int q4_wait_pos(const RunState* s, int pos);
 
-/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1 (default): fused sequence
- * (rmsnorm folded into the consumer GEMV, RoPE + KV write in the QKV epilogue). Resets captured graphs. */
+/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1: fused kernels (rmsnorm folded into the consumer
+ * GEMV, RoPE + KV write in the QKV epilogue: 5 launches/layer); 2 (default): additionally QKV -> attention -> o-proj
+ * (llama2_q4.cu:300-323) as ONE launch with in-launch hand-offs where the geometry has that form (multi-head, head 128,
+ * bins <= 512), 3 launches/layer. All levels produce identical bits. Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */
@@ -242,6 +244,9 @@ void q4_sampler_delete(Sampler* s);
 /* generate()'s state reset, llama2_q4.cu:461-463: pos = 0, copy prompt tokens into the shared ring */
 int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens);
 int q4_shared_pos(const RunState* s);
+/* Fusion level 2 waits inside a launch with BOUNDED spins; one that ran out sets a sticky device flag and the results
+ * from then on are invalid. Synchronises the stream; Q4_OK, or Q4_ERR_HIP with q4_last_error() set. */
+int q4_handoff_status(const RunState* s);
 int q4_shared_token(const RunState* s, int index);
 /* parity dumps: synchronise, then copy fp16 logits / a KV row / the residual to the host */
 int q4_get_logits(const Transformer* t, q4_half* host_out);

@@ -1,0 +1,265 @@
+// attention.h -- MultiHeadAttention (llama2_q4.cu:267-284) as ONE block per head: mat_vec_kernel_simple
+// (gpu_kernels.h:142-168) + softmax_kernel (:357-401) + vec_mat_kernel (:279-329) without the `att` round trip.
+// A K/V row of a head is head_size halves = LPR lanes x 16 B, so one wave instruction fetches 64/LPR positions,
+// coalesced. Pass 1 scores -> LDS (fp32, rounded through fp16 like the reference's `att`, :167), block max / exp /
+// sum (:373-396), pass 2 probabilities (rounded through fp16, :400) times V (:311). Scores never leave the CU.
+//
+// The same body serves the stand-alone kernel (attention_kernel) and the attention role of the fused launch
+// (layer_attn.hip, FUSED = true): there the block requests the cached rows of positions < pos at entry -- while the
+// QKV blocks of the same launch are still streaming their weights --, waits for its head's q / k / v producers, fetches
+// q and the row of position pos with sc1 loads, and publishes its output write-through for the o-proj blocks.
+#pragma once
+#include "gemv_q4.h"
+
+namespace q4 {
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    if (LPR >= 8) v += dpp_mov<0x141>(v);
+    if (LPR >= 16) v += dpp_mov<0x140>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16);
+    return v;
+}
+
+constexpr int ATT_NW = 16;   // waves per block of the split-context kernels
+
+struct AttArgs {
+    q4_half* output;             // [n_heads * head_size]
+    const q4_half* q;
+    const q4_half* key_cache;    // already offset to the layer
+    const q4_half* value_cache;
+    int head_size, kv_mul, kv_dim;
+    const int* pPos;
+    float alpha;                 // 1/sqrt(head_size), computed in double then cast (llama2_q4.cu:273)
+    int lds_scores;              // fp32 score slots in LDS (the sequence-length bin)
+    unsigned long long* dbg;     // profiling stamps (profiling build)
+};
+
+// 16-byte load of a row slice that another CU wrote INSIDE this launch: sc1 (served past the L1), through a buffer
+// descriptor so that hipcc's waitcnt pass tracks it like any other load
+__device__ __forceinline__ u32x4 load16_sc1(const q4_half* base, size_t half_index) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(half_index * 2), 0, 16);
+}
+template <bool SC1>
+__device__ __forceinline__ u32x4 load_row16(const q4_half* base, size_t half_index) {
+    if (SC1) return load16_sc1(base, half_index);
+    return *reinterpret_cast<const u32x4*>(base + half_index);
+}
+
+// U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
+template <int LPR, int U, int NW, bool FUSED>
+__device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
+    constexpr int R = 64 / LPR;            // positions per wave instruction
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
+    if (!FUSED && a.dbg) ts[0] = __builtin_readcyclecounter();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red_max = reinterpret_cast<float*>(smem);         // [16]
+    float* red_sum = red_max + 16;                           // [16]
+    float* outp = red_sum + 16;                              // [NW][head_size] output partials
+    float* sc = outp + NW * a.head_size;                     // [lds_scores] scores, then exps
+    const int head_size = a.head_size, kv_dim = a.kv_dim;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = tid >> 6;
+    const int row = lane / LPR, sub = lane % LPR;            // position within the instruction, 16-B slice of the row
+    constexpr int stride = NW * R;                           // positions per block step
+    constexpr int group = stride * U;                        // positions per block pass
+    const size_t hoff = (size_t)(h / a.kv_mul) * head_size + sub * 8;   // this lane's 16-B slice inside a cache row
+    const q4_half* kh = a.key_cache + hoff;
+    const q4_half* vh = a.value_cache + hoff;
+    if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
+    const int size = *a.pPos + 1;
+    if (!FUSED && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
+
+    // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
+    // context <= `group` positions (rows past the position are not requested at all). FUSED: the row of the current
+    // position does not exist yet -- it follows after the hand-off
+    const int ready = FUSED ? size - 1 : size;
+    u32x4 kv0[U], vv0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = wave * R + row + u * stride;
+        kv0[u] = (u32x4){0u, 0u, 0u, 0u};
+        vv0[u] = (u32x4){0u, 0u, 0u, 0u};
+        if (t < ready) {
+            kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)t * kv_dim);
+            vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)t * kv_dim);
+        }
+    }
+    u32x4 qv;
+    if (FUSED) {
+        // the head's q / k / v producer blocks of this launch (sc1 stores, drained, one arrival each)
+        if (tid == 0) spin_until(ho.wait + h, ho.wait_target, ho.error);
+        __syncthreads();
+        qv = load16_sc1(a.q, (size_t)h * head_size + sub * 8);
+        if (size - 1 < group) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = wave * R + row + u * stride;
+                if (t == size - 1) {
+                    kv0[u] = load16_sc1(a.key_cache, hoff + (size_t)t * kv_dim);     // wave-uniform base: the descriptor stays in SGPRs
+                    vv0[u] = load16_sc1(a.value_cache, hoff + (size_t)t * kv_dim);
+                }
+            }
+        }
+    } else {
+        qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
+    }
+
+    // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
+    float wmax = -INFINITY;
+    for (int g0 = 0; g0 < size; g0 += group) {
+        u32x4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (g0 == 0) {
+                kv[u] = kv0[u];
+            } else {
+                const int t = g0 + wave * R + row + u * stride;
+                const int tc = t < size ? t : size - 1;
+                kv[u] = load_row16<FUSED>(a.key_cache, hoff + (size_t)tc * kv_dim);   // (FUSED: may be the row written in this launch)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = g0 + wave * R + row + u * stride;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
+            s = row_sum<LPR>(s);
+            s = round_h(s * a.alpha);                                             // gpu_kernels.h:164-167
+            if (t < size) {
+                wmax = fmaxf(wmax, s);
+                if (sub == 0) sc[t] = s;
+            }
+        }
+    }
+    wmax = wave_max(wmax);
+    if (!FUSED && a.dbg) ts[2] = __builtin_readcyclecounter();
+    if (lane == 0) red_max[wave] = wmax;
+    __syncthreads();                                                              // barrier 1: scores + wave maxima
+    if (!FUSED && a.dbg) ts[3] = __builtin_readcyclecounter();
+
+    // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
+    const float m = row16_max(red_max[lane & 15]);
+    float sum = 0.f;
+    for (int t = tid; t < size; t += NW * 64) {
+        const float e = expf(sc[t] - m);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red_sum[wave] = sum;
+    __syncthreads();                                                              // barrier 2: exps + wave sums
+    if (!FUSED && a.dbg) ts[4] = __builtin_readcyclecounter();
+    // fixed order: DPP tree over the 16 wave sums
+    sum = row16_sum(red_sum[lane & 15]);
+    const float inv_sum = 1.0f / sum;       // one IEEE division; p = e * inv_sum is within 1 fp32 ulp of e / sum (:400)
+
+    // ---- pass 2: att . V -----------------------------------------------------------------------------
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    for (int g0 = 0; g0 < size; g0 += group) {
+        u32x4 vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (g0 == 0) {
+                vv[u] = vv0[u];
+            } else {
+                const int t = g0 + wave * R + row + u * stride;
+                const int tc = t < size ? t : size - 1;
+                vv[u] = load_row16<FUSED>(a.value_cache, hoff + (size_t)tc * kv_dim);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = g0 + wave * R + row + u * stride;
+            const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const h2 v2 = as_h2(vv[u][e]);
+                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);          // :311
+                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+            }
+        }
+    }
+    // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
+    // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
+    // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
+    if constexpr (LPR == 16) {
+        const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
+        const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
+        outp[wave * head_size + sub * 8 + row] = s0;
+        outp[wave * head_size + sub * 8 + 4 + row] = s1;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float v = acc[e];
+            if (LPR <= 32) v += __shfl_xor(v, 32);
+            if (LPR <= 16) v += __shfl_xor(v, 16);
+            if (LPR <= 8) v += __shfl_xor(v, 8);
+            if (LPR <= 4) v += __shfl_xor(v, 4);
+            acc[e] = v;
+        }
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+        }
+    }
+    if (!FUSED && a.dbg) ts[5] = __builtin_readcyclecounter();
+    __syncthreads();                                                              // barrier 3: output partials
+    if (FUSED) {
+        // 16 bytes per thread (head_size / 8 threads of wave 0 .. ), written through for the o-proj blocks of this launch
+        if ((int)tid < head_size / 8) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float s2[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int n = tid * 8 + e * 2 + k;
+                    float part[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) s += part[w];
+                    s2[k] = s;
+                }
+                const h2 hh = {(f16_t)s2[0], (f16_t)s2[1]};
+                pk[e] = as_u(hh);
+            }
+            q4_half* dst = a.output + (size_t)h * head_size + tid * 8;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pk) : "memory");
+        }
+        drain_stores();
+        __syncthreads();            // head_size / 8 may span two waves (head 256 .. 1024): every storing wave has drained
+        if (tid == 0) __hip_atomic_fetch_add(ho.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        for (int n = tid; n < head_size; n += NW * 64) {
+            float part[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];       // independent LDS reads
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) s += part[w];
+            a.output[(size_t)h * head_size + n] = f2h(s);
+        }
+        if (a.dbg && lane == 0) {
+            ts[6] = __builtin_readcyclecounter();
+            unsigned long long* d = a.dbg + ((size_t)h * NW + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = ts[i];
+        }
+    }
+}
+
+template <int LPR, int U = 4, int NW = ATT_NW>
+__global__ void __launch_bounds__(NW * 64) attention_kernel(const AttArgs a) {
+    attention_body<LPR, U, NW, false>(a, blockIdx.x, Handoff{});
+}
+
+}  // namespace q4

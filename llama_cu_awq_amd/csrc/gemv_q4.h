@@ -67,6 +67,36 @@ struct GemvArgs {
     int early;                 // waves in the first `early` slots of a SIMD issue their weight loads before the staging ends
 };
 
+// In-launch hand-off (layer_attn.hip: QKV -> attention -> o-proj as ONE launch). ROLE_PRODUCER blocks publish their
+// outputs with write-through (sc1) stores, drain them and bump `signal[...]`; ROLE_CONSUMER blocks put every weight load
+// in flight FIRST, then one lane polls `wait` (relaxed agent-scope loads, s_sleep between polls, bounded) and the block
+// reads its activation vector with sc1 loads. Forms from MI355X_MICROARCH.md ("Valid forms": sc1 payload -> vmcnt(0) ->
+// flag; consumer: relaxed poll -> sc1 loads). ROLE_NONE compiles to the stand-alone kernel, bit for bit.
+constexpr int ROLE_NONE = 0, ROLE_PRODUCER = 1, ROLE_CONSUMER = 2;
+struct Handoff {
+    unsigned* signal;      // producer: word(s) to bump (QKV: one per head, indexed by the block's head)
+    unsigned* wait;        // consumer: word to poll
+    unsigned wait_target;  // consumer: value that means "all producers done"
+    unsigned* done;        // consumer: finished-consumer count; the last one clears every word for the next launch
+    unsigned done_target;
+    unsigned* clear;       // words [0, clear_n) cleared by the last consumer
+    int clear_n;
+    unsigned* error;       // set to 1 when a bounded spin ran out (results are garbage then; the host reports it)
+};
+
+// bounded spin on a monotonic counter: ~0.1 us per poll, 2^21 polls ~ 0.2 s, then give up loudly instead of hanging the GPU
+__device__ __forceinline__ void spin_until(const unsigned* word, unsigned target, unsigned* error) {
+    for (unsigned i = 0; i < (1u << 21); i++) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (error) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_half_sc1(q4_half* p, uint16_t v) {
+    asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((unsigned)v) : "memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int MODE>
 struct ModeTraits { static constexpr int NMAT = (MODE == MODE_FFN) ? 2 : 1; };
 
@@ -120,8 +150,9 @@ struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT
 // HALF: the column's last k-slot holds at most 32 uint4 (K = 5120: 160 = 2 x 64 + 32). Instead of running that slot with
 // half of the lanes multiplying zero padding, lanes 0-31 take it for column c and lanes 32-63 for column c + 1 of each
 // column pair: one load and one dequant-dot evaluation per PAIR (13B q/k/v/o/gate/up: 12 -> 10 per wave).
-template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
-__global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL, int KS, bool HALF, int ROLE>
+__device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned vbx, const unsigned vby, const Handoff& ho) {
+    static_assert(ROLE == ROLE_NONE || (KS == 1 && ABL != 3), "hand-off roles: no K split, no time stamps");
     static_assert(!HALF || (KS == 1 && COLS % 2 == 0), "shared half slot: no K split, column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
@@ -138,14 +169,14 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     const unsigned lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: column offsets stay in SGPRs
     const int nw = blockDim.x >> 6;
-    const int wg = blockIdx.x * (nw / KS) + wave / KS;   // global column-group index
+    const int wg = vbx * (nw / KS) + wave / KS;   // global column-group index
     const int khalf = wave % KS;
     const int sbase = khalf * SLOTS;            // first k-slot of this wave
     const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
-    const int mat0 = (MODE == MODE_QKV) ? blockIdx.y : 0;
+    const int mat0 = (MODE == MODE_QKV) ? vby : 0;
     // grouped-query attention: k and v have kv_dim < dim columns; the launch grid is sized for q, surplus blocks leave
     const int N = (MODE == MODE_QKV && mat0 != 0 && a.N_kv > 0) ? a.N_kv : a.N;
-    if (MODE == MODE_QKV && (int)(blockIdx.x * (blockDim.x >> 6)) * COLS >= N) return;
+    if (MODE == MODE_QKV && (int)(vbx * (blockDim.x >> 6)) * COLS >= N) return;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ABL == 3) { ts[0] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }   // [6]: 100 MHz, same on every XCD
 
@@ -179,13 +210,21 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 
     // ---- 1. activation loads first: their wait (counted vmcnt) leaves the weight loads in flight ----
     u32x4 xraw[TS], wraw[TS];
+    auto load_x = [&]() {
 #pragma unroll
-    for (int i = 0; i < TS; i++) {
-        const unsigned u = tid + i * blockDim.x;
-        const unsigned uc = u < nchunks ? u : nchunks - 1;  // clamped, branch-free
-        xraw[i] = reinterpret_cast<const u32x4*>(a.x)[uc];
-        if (NORM) wraw[i] = reinterpret_cast<const u32x4*>(a.rms_w)[uc];
-    }
+        for (int i = 0; i < TS; i++) {
+            const unsigned u = tid + i * blockDim.x;
+            const unsigned uc = u < nchunks ? u : nchunks - 1;  // clamped, branch-free
+            if (ROLE == ROLE_CONSUMER) {   // produced inside this launch by other CUs: sc1 load (served past the L1)
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.K * 2, 0x00020000);
+                xraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, uc * 16, 0, 16);
+            } else {
+                xraw[i] = reinterpret_cast<const u32x4*>(a.x)[uc];
+            }
+            if (NORM) wraw[i] = reinterpret_cast<const u32x4*>(a.rms_w)[uc];
+        }
+    };
+    if (ROLE != ROLE_CONSUMER) load_x();
 
     // ---- 2. weight / zero / scale loads: the first PRE slots go out BEFORE the activation staging (so HBM is
     // busy while the block normalises x), the rest right after it. Measured with s_memtime stamps: issuing every
@@ -289,6 +328,12 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
     };
     if (early) {    // give the waves that entered last time to queue their x loads (bits 8+ of a.early, 128-cycle steps)
         for (int i = a.early >> 8; i > 0; i--) __builtin_amdgcn_s_sleep(2);
+    }
+    if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers, then fetch x
+        static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
+        if (tid == 0) spin_until(ho.wait, ho.wait_target, ho.error);
+        __syncthreads();
+        load_x();
     }
     if (ABL != 4 && !early) stage_tail();      // (ABL 4: no staging at all, garbage x -- the kernel without the x chain)
     __builtin_amdgcn_sched_barrier(0);
@@ -427,7 +472,26 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
             }
             r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
-        if (writer && n < N) out[n] = f2h(r);
+        if (ROLE == ROLE_PRODUCER) {
+            // write-through stores, drained, then ONE arrival per block on the head's counter (all of a block's columns
+            // belong to one head: the launcher checks head_size/2 % (2 * waves) == 0)
+            if (writer && n < N) store_half_sc1(out + n, f2h(r));
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) {
+                const int hb = (int)(vbx * (blockDim.x >> 6) * 2) / hp;
+                __hip_atomic_fetch_add(ho.signal + hb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (writer && n < N) out[n] = f2h(r);
+        }
+    }
+    if (ROLE == ROLE_CONSUMER) {   // the last consumer block to finish leaves every hand-off word at zero for the next launch
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ho.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == ho.done_target - 1u)
+                for (int i = 0; i < ho.clear_n; i++) __hip_atomic_store(ho.clear + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (ABL == 3 && a.dbg != nullptr && lane == 0) {
         ts[7] = __builtin_readcyclecounter();
@@ -435,6 +499,11 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)
 #pragma unroll
         for (int i = 0; i < 8; i++) d[i] = ts[i];
     }
+}
+
+template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
+__global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
+    gemv_q4_body<MODE, SLOTS, COLS, NORM, ABL, KS, HALF, ROLE_NONE>(a, blockIdx.x, blockIdx.y, Handoff{});
 }
 
 static inline int cu_count() {

@@ -192,6 +192,7 @@ double q4_generate(Transformer* transformer, struct Tokenizer* tokenizer, Sample
     double time = (end - start) / 1000.0;
     int timed_tokens = pos - 1;
     printf("\nachieved tok/s: %f. Tokens: %d, seconds: %g\n", timed_tokens / time, timed_tokens, time);   // :489
+    die_on(q4_handoff_status(state));          // a bounded in-launch wait that ran out invalidates the run: say so and exit
     free(prompt_tokens);
     if (timed_tokens_out) *timed_tokens_out = timed_tokens;
     if (seconds_out) *seconds_out = time;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "gemv_q4.h"
+#include "attention.h"
 
 namespace q4 {
 
@@ -114,184 +115,7 @@ __global__ void rope_kernel(q4_half* sq, q4_half* sk_base, int num_kv_heads, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// MultiHeadAttention (llama2_q4.cu:267-284) as ONE kernel per layer: block = one head, 16 waves.
-// A K/V row of a head is head_size halves = LPR lanes x 16 B, so one wave instruction fetches 64/LPR
-// positions, coalesced. Pass 1 scores -> LDS (fp32, rounded through fp16 like the reference's `att`,
-// gpu_kernels.h:167), block max / exp / sum (:373-396), pass 2 probabilities (rounded through fp16, :400)
-// times V (:311). Scores never leave the CU; `att` in HBM is not touched.
-template <int LPR>
-__device__ __forceinline__ float row_sum(float v) {
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    if (LPR >= 8) v += dpp_mov<0x141>(v);
-    if (LPR >= 16) v += dpp_mov<0x140>(v);
-    if (LPR >= 32) v += __shfl_xor(v, 16);
-    return v;
-}
-
-constexpr int ATT_NW = 16;   // waves per attention block (one block per head)
-
-template <int LPR, int U = 4, int NW = ATT_NW>
-__global__ void __launch_bounds__(NW * 64) attention_kernel(q4_half* output, const q4_half* q, const q4_half* key_cache,
-                                                                const q4_half* value_cache, int head_size, int kv_mul,
-                                                                int kv_dim, const int* pPos, float alpha, int lds_scores,
-                                                                unsigned long long* dbg) {
-    constexpr int R = 64 / LPR;            // positions per wave instruction
-    // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
-    if (dbg) ts[0] = __builtin_readcyclecounter();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red_max = reinterpret_cast<float*>(smem);         // [16]
-    float* red_sum = red_max + 16;                           // [16]
-    float* outp = red_sum + 16;                              // [NW][head_size] output partials
-    float* sc = outp + NW * head_size;                       // [lds_scores] scores, then exps
-    const int h = blockIdx.x;
-    const unsigned tid = threadIdx.x, lane = tid & 63u;
-    const int wave = tid >> 6;
-    const int row = lane / LPR, sub = lane % LPR;            // position within the instruction, 16-B slice of the row
-    constexpr int stride = NW * R;                           // positions per block step
-    constexpr int group = stride * U;                        // positions per block pass (256 for head 128)
-    const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-    const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-    if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
-    const int size = *pPos + 1;
-    if (dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
-
-    // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
-    // context <= `group` positions (rows are clamped to pos, so only cache-warm rows are touched)
-    u32x4 kv0[U], vv0[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int t = wave * R + row + u * stride;
-        kv0[u] = (u32x4){0u, 0u, 0u, 0u};
-        vv0[u] = (u32x4){0u, 0u, 0u, 0u};
-        if (t < size) {                                      // rows past the position are not requested at all
-            kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)t * kv_dim);
-            vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)t * kv_dim);
-        }
-    }
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
-
-    // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
-    float wmax = -INFINITY;
-    for (int g0 = 0; g0 < size; g0 += group) {
-        u32x4 kv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (g0 == 0) {
-                kv[u] = kv0[u];
-            } else {
-                const int t = g0 + wave * R + row + u * stride;
-                const int tc = t < size ? t : size - 1;
-                kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = g0 + wave * R + row + u * stride;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
-            s = row_sum<LPR>(s);
-            s = round_h(s * alpha);                                               // gpu_kernels.h:164-167
-            if (t < size) {
-                wmax = fmaxf(wmax, s);
-                if (sub == 0) sc[t] = s;
-            }
-        }
-    }
-    wmax = wave_max(wmax);
-    if (dbg) ts[2] = __builtin_readcyclecounter();
-    if (lane == 0) red_max[wave] = wmax;
-    __syncthreads();                                                              // barrier 1: scores + wave maxima
-    if (dbg) ts[3] = __builtin_readcyclecounter();
-
-    // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
-    const float m = row16_max(red_max[lane & 15]);
-    float sum = 0.f;
-    for (int t = tid; t < size; t += NW * 64) {
-        const float e = expf(sc[t] - m);
-        sc[t] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red_sum[wave] = sum;
-    __syncthreads();                                                              // barrier 2: exps + wave sums
-    if (dbg) ts[4] = __builtin_readcyclecounter();
-    // fixed order: DPP tree over the 16 wave sums
-    sum = row16_sum(red_sum[lane & 15]);
-    const float inv_sum = 1.0f / sum;       // one IEEE division; p = e * inv_sum is within 1 fp32 ulp of e / sum (:400)
-
-    // ---- pass 2: att . V -----------------------------------------------------------------------------
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (int g0 = 0; g0 < size; g0 += group) {
-        u32x4 vv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (g0 == 0) {
-                vv[u] = vv0[u];
-            } else {
-                const int t = g0 + wave * R + row + u * stride;
-                const int tc = t < size ? t : size - 1;
-                vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = g0 + wave * R + row + u * stride;
-            const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const h2 v2 = as_h2(vv[u][e]);
-                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);          // :311
-                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
-            }
-        }
-    }
-    // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
-    // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
-    // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
-    if constexpr (LPR == 16) {
-        const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
-        const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
-        outp[wave * head_size + sub * 8 + row] = s0;
-        outp[wave * head_size + sub * 8 + 4 + row] = s1;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float v = acc[e];
-            if (LPR <= 32) v += __shfl_xor(v, 32);
-            if (LPR <= 16) v += __shfl_xor(v, 16);
-            if (LPR <= 8) v += __shfl_xor(v, 8);
-            if (LPR <= 4) v += __shfl_xor(v, 4);
-            acc[e] = v;
-        }
-        if (lane < LPR) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
-        }
-    }
-    if (dbg) ts[5] = __builtin_readcyclecounter();
-    __syncthreads();                                                              // barrier 3: output partials
-    for (int n = tid; n < head_size; n += NW * 64) {
-        float part[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];           // independent LDS reads
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) s += part[w];
-        output[(size_t)h * head_size + n] = f2h(s);
-    }
-    if (dbg && lane == 0) {
-        ts[6] = __builtin_readcyclecounter();
-        unsigned long long* d = dbg + ((size_t)h * NW + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; i++) d[i] = ts[i];
-    }
-}
-
+// MultiHeadAttention: attention_body / attention_kernel live in attention.h (shared with the fused launch, layer_attn.hip)
 // Long contexts: the same block, but one per (head, 256-position chunk) so that all CUs pull on the KV cache (at
 // pos 2047 a layer's K+V is 32 MB; 32 single-head blocks would stream it at a few CUs' worth of bandwidth). Each
 // block leaves flash-decode partials -- running max m, sum l of exp(s - m), un-normalised acc[head_size] in fp32 --
@@ -665,6 +489,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     const size_t smem = (size_t)(32 + ATT_NW * head_size + max_seq_len) * 4;
     if (smem > 160 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;                          // > ~38K positions
     dim3 grid(num_heads);
+    const AttArgs aa = {output, q, key_cache, value_cache, head_size, kv_mul, kv_dim, pPos, alpha, max_seq_len, g_dbg};
 #define Q4_ATT(L)                                                                                                  \
     {                                                                                                              \
         static size_t opted = 64 * 1024;   /* per instantiation: opt in to more LDS only when a launch needs more */ \
@@ -673,8 +498,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
                                        (int)smem));                                                                \
             opted = smem;                                                                                          \
         }                                                                                                          \
-        Q4_LAUNCH((attention_kernel<L>), grid, block, smem, output, q, key_cache, value_cache, head_size, kv_mul,  \
-                  kv_dim, pPos, alpha, max_seq_len, g_dbg);                                                        \
+        Q4_LAUNCH((attention_kernel<L>), grid, block, smem, aa);                                                   \
     }
     switch (head_size) {
         case 32: Q4_ATT(4) break;
@@ -682,8 +506,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
         case 128:
             if (max_seq_len <= 128) {   // first bin: 8 waves cover the 128 positions in one pass (no clamped duplicate loads,
                                         // cheaper barriers): 7B -n 256 +1 % over the 16-wave block
-                Q4_LAUNCH((attention_kernel<16, 4, 8>), grid, dim3(8 * 64), smem, output, q, key_cache, value_cache, head_size,
-                          kv_mul, kv_dim, pPos, alpha, max_seq_len, g_dbg);
+                Q4_LAUNCH((attention_kernel<16, 4, 8>), grid, dim3(8 * 64), smem, aa);
             } else Q4_ATT(16)
             break;
         case 256: Q4_ATT(32) break;

@@ -14,7 +14,7 @@
 namespace q4 {
 
 hipStream_t g_stream = nullptr;
-int g_fusion = 1;
+int g_fusion = 2;
 int g_use_graphs = 1;
 int g_quiet = 0;
 char g_last_error[512] = "";
@@ -34,13 +34,20 @@ struct Slabs {
     void* shared = nullptr;
     void* logits_array = nullptr;
     float2* rope_table = nullptr;   // [seq_len][head_size/2] (cos, sin), lives exactly as long as the Transformer
+    unsigned* sync = nullptr;       // hand-off words of the fused attention-block launch (n_heads + 3), zero between launches
 };
 static std::map<const Transformer*, Slabs> g_slabs;
 // the network entry points take (Config, RunState, TransformerWeights), not the Transformer: tables are found by RunState
 static std::map<const RunState*, const float2*> g_rope_by_state;
+static std::map<const RunState*, unsigned*> g_sync_by_state;
+static std::map<const RunState*, size_t> g_sync_words;   // count per model: n_heads + 2 (the error flag behind them is sticky)
 const float2* rope_table_of(const RunState* s) {
     auto it = g_rope_by_state.find(s);
     return it == g_rope_by_state.end() ? nullptr : it->second;
+}
+static unsigned* sync_words_of(const RunState* s) {
+    auto it = g_sync_by_state.find(s);
+    return it == g_sync_by_state.end() ? nullptr : it->second;
 }
 
 // graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
@@ -116,7 +123,7 @@ int q4_memset(void* dst, int value, size_t bytes) {
     return Q4_OK;
 }
 
-void q4_set_fusion(int level) { g_fusion = level ? 1 : 0; q4_reset_graphs(); }
+void q4_set_fusion(int level) { g_fusion = level < 0 ? 0 : level > 2 ? 2 : level; q4_reset_graphs(); }
 int q4_get_fusion(void) { return g_fusion; }
 void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
 void q4_set_quiet(int quiet) { g_quiet = quiet; }
@@ -311,6 +318,14 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     g_slabs[t] = slabs;
     if (rc) { q4_free_transformer(t); return rc; }
     if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
+    if (hipMalloc((void**)&slabs.sync, (p->n_heads + 3) * sizeof(unsigned)) == hipSuccess) {
+        hipMemset(slabs.sync, 0, (p->n_heads + 3) * sizeof(unsigned));
+        g_slabs[t] = slabs;
+        g_sync_by_state[&t->state] = slabs.sync;
+        g_sync_words[&t->state] = (size_t)p->n_heads + 2;
+    } else {
+        (void)hipGetLastError();    // no hand-off words: the network runs its five-launch sequence
+    }
     return Q4_OK;
 }
 
@@ -325,7 +340,10 @@ void q4_free_transformer(Transformer* t) {                                      
         if (it->second.shared) hipHostFree(it->second.shared);
         if (it->second.logits_array) hipFree(it->second.logits_array);
         if (it->second.rope_table) hipFree(it->second.rope_table);
+        if (it->second.sync) hipFree(it->second.sync);
         g_rope_by_state.erase(&t->state);
+        g_sync_by_state.erase(&t->state);
+        g_sync_words.erase(&t->state);
         g_slabs.erase(it);
     }
     free(t->weights.layers);
@@ -386,6 +404,7 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
     const int kv_mul = p->n_heads / p->n_kv_heads;
     const float2* rope_table = rope_table_of(s);
+    unsigned* sync = sync_words_of(s);
 
     Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
@@ -394,6 +413,12 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
         // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
         const long long loff = (long long)l * p->seq_len * kv_dim;
+        if (g_fusion >= 2 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
+            // :300-323 in ONE launch: QKV blocks, attention heads and o-proj blocks hand over inside the launch (layer_attn.hip)
+            Q4_UNLESS(7, launch_attention_block(x, s->xb, s->q, s->key_cache, s->value_cache, L->rms_att_weight, &L->wq_q, &L->wq_k,
+                                                &L->wq_v, &L->wq_o, dim, p->n_heads, loff, pPos, p->rope_theta, rope_table,
+                                                seq_len_bin, sync));
+        } else {
         if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
@@ -413,6 +438,7 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
                                       seq_len_bin, pPos, (float*)s->att,
                                       (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half)));   // :320
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
+        }
         if (g_fusion) {
             Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
         } else {
@@ -575,6 +601,10 @@ int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, 
 // ---------------------------------------------------------------------------------------------------
 int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens) {
     Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
+    if (unsigned* sync = sync_words_of(s)) {     // hand-off words are zero between launches; also after a failed one
+        auto it = g_sync_words.find(s);
+        Q4_HIP(hipMemsetAsync(sync, 0, (it != g_sync_words.end() ? it->second : 0) * sizeof(unsigned), g_stream));
+    }
     Q4_HIP(hipStreamSynchronize(g_stream));
     s->shared_data->pos = 0;                                                       // :462
     if (prompt_tokens && num_prompt_tokens > 0)
@@ -582,6 +612,21 @@ int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_toke
     return Q4_OK;
 }
 int q4_shared_pos(const RunState* s) { return s->shared_data->pos; }
+// The in-launch hand-offs of fusion level 2 spin for a bounded time; a spin that ran out sets a sticky device flag
+// (results from then on are invalid). Synchronises the stream and reports it.
+int q4_handoff_status(const RunState* s) {
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    unsigned* sync = sync_words_of(s);
+    auto it = g_sync_words.find(s);
+    if (!sync || it == g_sync_words.end()) return Q4_OK;
+    unsigned flag = 0;
+    Q4_HIP(hipMemcpy(&flag, sync + it->second, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) {
+        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 2)");
+        return Q4_ERR_HIP;
+    }
+    return Q4_OK;
+}
 // Wait until the device has published position >= pos (argmax_kernel / sample_scan_kernel write the token, fence, then
 // SharedData::pos -- "unblocks the CPU", gpu_kernels.h:490). Spins on the pinned word; falls back to the stream state
 // so that a failed launch cannot hang the host.
@@ -647,6 +692,7 @@ double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_token
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     const int timed_tokens = pos - 1;                                              // :488
+    if (q4_handoff_status(&t->state)) return -1.0;                                 // a timed-out hand-off: fail loudly
     if (out_tokens) {
         const int n = (pos < steps ? pos : steps) + 1;
         for (int i = 0; i < n && i < Q4_MAX_SEQ_LEN; i++) out_tokens[i] = t->state.shared_data->tokens[i];

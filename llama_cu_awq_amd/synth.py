@@ -37,6 +37,10 @@ GEOMETRIES = {
     # Llama-2-70B / CodeLlama-34B traits at test size: GQA (kv_mul 4), head 128, down projection with K > 16384
     # (the K-split kernel's long form), rope_theta 1e6
     "longk_gqa": (1024, 20480, 2, 8, 2, 512, 128, 1000000.0),
+    # the geometries that have a fused attention-block launch (multi-head, head 128): K = dim in two k-slots (7B-like) and
+    # in three with the shared half slot (13B-like), contexts long enough to cross the 128 / 256 / 512 / 1024 bins
+    "head128": (2560, 3584, 2, 20, 20, 512, 1100, 10000.0),
+    "head128_k5120": (5120, 1408, 1, 40, 40, 512, 300, 10000.0),
     # the sampler at production vocabulary sizes on a one-layer body: 32000 = the register/LDS path with 32 keys per
     # thread, 40000 = the global-memory fallback (> 32 x 1024 entries)
     "v32k": (64, 96, 1, 2, 2, 32000, 32, 10000.0),

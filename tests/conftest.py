@@ -39,6 +39,27 @@ def orc():
     return oracle
 
 
+_OBSERVED = {}
+
+
+@pytest.fixture(scope="session")
+def observed():
+    """Worst-case deviations the parity tests actually measured (the written tolerances are ~3x these). Dumped to
+    gpurun_out/parity_observed.json at session end; the committed copy lives under profiles/."""
+    import json
+    yield _OBSERVED
+    if _OBSERVED:
+        out = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(out, exist_ok=True)
+            path = os.path.join(out, "parity_observed.json")
+            old = json.load(open(path)) if os.path.exists(path) else {}
+            old.update(_OBSERVED)
+            json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+        except OSError:
+            pass
+
+
 @pytest.fixture()
 def rng():
     return np.random.default_rng(1234)

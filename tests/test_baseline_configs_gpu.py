@@ -12,7 +12,7 @@ against the CPU restatement (oracle/q4_oracle.c) and the unrounded double forwar
 Tolerances. At 32-40 layers of RANDOM weights two valid fp16 evaluations of the network drift apart by a few 1e-2 of
 max(1,|logit|); the yardstick is the same network in double without rounding (orc_forward_f64): the HIP path may be at
 most 2x as far from it as the reference-order restatement (+1e-3). Against the restatement itself the bound is 3x the
-measured worst case. Tokens must be equal except at near-ties of the restatement's top two logits."""
+measured worst case (0.050 at 7B, 0.059 at 13B: profiles/r02_parity_observed.json -> 0.15). Tokens must be equal except at near-ties of the restatement's top two logits."""
 import ctypes as C
 import os
 
@@ -51,7 +51,7 @@ def _ring(t):
     return np.ctypeslib.as_array((C.c_int * t.config.seq_len).from_address(base + 4))
 
 
-def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement):
+def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement, rec=None):
     """Feed both evaluations the same tokens; returns (worst rel err vs restatement, tokens compared, near-tie count)."""
     t.reset(prompt)
     ring = _ring(t)
@@ -70,6 +70,9 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement):
             exact = m.forward_f64(toks[pos], pos, cap=f64_steps)
             eg, er = _rel(got, exact), _rel(ref, exact)
             assert eg <= 2.0 * er + 1e-3, "pos %d: GPU %g vs restatement %g from the unrounded forward" % (pos, eg, er)
+            if rec is not None:
+                rec["vs_f64_gpu_max"] = max(rec.get("vs_f64_gpu_max", 0.0), eg)
+                rec["vs_f64_restatement_max"] = max(rec.get("vs_f64_restatement_max", 0.0), er)
         assert t.pos() == pos + 1
         if gen:
             r32 = ref.astype(np.float32)
@@ -82,38 +85,41 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement):
                 ring[pos + 1] = want                      # keep both evaluations on the restatement's sequence
             compared += 1
             toks.append(want)
+    if rec is not None:
+        rec.update({"logits_max_rel_vs_restatement": worst, "tokens_compared": compared, "near_ties": ties, "positions": steps})
     return worst, compared, ties
 
 
-def test_config2_llama2_7b_decode_32_positions(q4, orc, m7b):
+def test_config2_llama2_7b_decode_32_positions(q4, orc, m7b, observed):
     t = q4.Transformer(m7b)
     m = orc.Model(m7b)
-    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 32, 10, bound_vs_restatement=0.12)   # measured 0.027-0.04
+    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 32, 10, bound_vs_restatement=0.15,   # measured 0.027-0.04
+                                     rec=observed.setdefault("config2_7b", {}))
     assert compared == 25 and ties <= 2
     # KV rows of the last position: layer 0 sees only the embedding (one GEMV deep), the last layer the whole stack
     rk, rv = m.kv()
-    for layer, tol in ((0, 2e-3), (t.config.n_layers - 1, 0.12)):
+    for layer, tol in ((0, 2e-3), (t.config.n_layers - 1, 0.1)):
         gk, gv = t.kv_row(layer, 31)
         assert _rel(gk, rk[layer, 31]) <= tol and _rel(gv, rv[layer, 31]) <= tol, layer
     t.close()
     m.close()
 
 
-def test_config3_llama2_13b_decode_8_positions(q4, orc):
+def test_config3_llama2_13b_decode_8_positions(q4, orc, observed):
     path = _model("13b")
     t = q4.Transformer(path)
     m = orc.Model(path)
-    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 9, 4, bound_vs_restatement=0.12)
+    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 9, 4, bound_vs_restatement=0.15, rec=observed.setdefault("config3_13b", {}))
     assert compared == 2
     t.close()
     m.close()
 
 
-def test_grouped_query_model_at_mistral_7b_geometry(q4, orc):
+def test_grouped_query_model_at_mistral_7b_geometry(q4, orc, observed):
     path = _model("mistral7b")
     t = q4.Transformer(path)
     m = orc.Model(path)
-    _lockstep(q4, t, m, PROMPT, 4, 2, bound_vs_restatement=0.12)
+    _lockstep(q4, t, m, PROMPT, 4, 2, bound_vs_restatement=0.15, rec=observed.setdefault("mistral7b_gqa", {}))
     t.close()
     m.close()
 
@@ -131,7 +137,7 @@ def _kv_to_host(q4, t):
 
 
 @pytest.mark.parametrize("target", [1100, 2040])
-def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target):
+def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target, observed):
     """Decode `target` positions through run_transformer's captured graphs (every sequence-length bin up to 2048, the
     split-context attention from bin 1024 on), then compare ONE more step with the restatement started from the GPU's
     own KV cache -- no 2000-step CPU run, and every cached position takes part in the compared step's attention."""
@@ -153,11 +159,16 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     assert t.pos() == target + 1
     # layer 0's K/V row depends on the embedding only; layer 1's on layer 0's attention over all `target` cached positions
     rk, rv = m.kv()
-    for layer, tol in ((0, 2e-3), (1, 6e-3), (t.config.n_layers - 1, 0.12)):
+    rec = observed.setdefault("config4_7b_pos%d" % target, {"tok_s_to_target": tps})
+    # K rows carry RoPE at a large angle (two 1-ulp GEMV outputs rotated: up to 4 fp16 ulps), V rows are one GEMV deep
+    for layer, ktol, vtol in ((0, 8e-3, 3e-3), (1, 2.4e-2, 1.2e-2), (t.config.n_layers - 1, 0.1, 0.1)):
         gk, gv = t.kv_row(layer, target)
-        assert _rel(gk, rk[layer, target]) <= tol and _rel(gv, rv[layer, target]) <= tol, (layer, _rel(gk, rk[layer, target]), _rel(gv, rv[layer, target]))
+        ek, ev = _rel(gk, rk[layer, target]), _rel(gv, rv[layer, target])
+        rec["layer%d_k_max_rel" % layer], rec["layer%d_v_max_rel" % layer] = ek, ev
+        assert ek <= ktol and ev <= vtol, (layer, ek, ev)
     e = _rel(got, ref)
-    assert e <= 0.12, e
+    rec["logits_max_rel_vs_restatement"] = e
+    assert e <= 0.15, e
     r32 = ref.astype(np.float32)
     top2 = np.sort(r32)[-2:]
     if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):
@@ -166,7 +177,7 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     m.close()
 
 
-def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b):
+def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b, observed):
     npos = 64
     rng = np.random.default_rng(5)
     toks = np.concatenate([[1], rng.integers(3, 32000, size=npos)]).astype(np.int32)
@@ -180,8 +191,10 @@ def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b):
         exact = m.forward_f64(int(toks[i]), i, cap=n64)
         eg, er = _rel(glog[i], exact), _rel(rlog[i], exact)
         assert eg <= 2.0 * er + 1e-3, (i, eg, er)
-    assert _rel(glog, rlog) <= 0.12
+    assert _rel(glog, rlog) <= 0.15
     rppl = orc.compute_perplexity(toks[1:npos + 1], rlog)
+    observed["config5_7b_perplexity"] = {"positions": npos, "perplexity_gpu": float(ppl), "perplexity_restatement": float(rppl),
+                                         "logits_max_rel_vs_restatement": _rel(glog, rlog)}
     assert abs(ppl - rppl) <= 5e-3 * rppl, (ppl, rppl)            # perplexity within 0.5 %
     t.close()
     m.close()

@@ -1,5 +1,6 @@
 """GPU path against the COMMITTED fixture (tests/golden/micro_model.bin + expected logits / KV / tokens recorded from
 the CPU restatement by tests/golden/make_goldens.py)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -20,24 +21,27 @@ def test_micro_model_against_committed_goldens(q4, fusion):
         prompt = exp["prompt"]
         t.reset(prompt)
         ref_logits = exp["logits"].astype(np.float32)
-        agree = 0
+        ring = np.ctypeslib.as_array((C.c_int * t.config.seq_len).from_address(t.state.contents.shared_data + 4))
+        agree = checked = 0
         for pos in range(20):
             t.run_transformer(pos >= len(prompt) - 1)
             q4.synchronize()
             got = t.logits().astype(np.float32)
-            assert (np.abs(got - ref_logits[pos]) <= 3e-2 * np.maximum(1.0, np.abs(ref_logits[pos]))).all(), pos
+            # measured worst case on this model: 1.2e-4 (one fp16 ulp of a 0.4 logit); bound = 3x
+            assert (np.abs(got - ref_logits[pos]) <= 4e-4 * np.maximum(1.0, np.abs(ref_logits[pos]))).all(), pos
             if pos >= len(prompt) - 1:
                 top2 = np.sort(ref_logits[pos])[-2:]
-                if top2[1] - top2[0] > 4e-3:
-                    assert t.token(pos + 1) == exp["tokens"][pos + 1]
+                if top2[1] - top2[0] > 5e-4:                         # every token that is not a near-tie must be equal
+                    assert t.token(pos + 1) == exp["tokens"][pos + 1], pos
                     agree += 1
-                if t.token(pos + 1) != exp["tokens"][pos + 1]:
-                    break                                            # a near-tie diverged: later positions are a different sequence
-        assert agree >= 3
+                checked += 1
+                ring[pos + 1] = exp["tokens"][pos + 1]               # stay on the recorded sequence through a near-tie
+        assert checked == 20 - (len(prompt) - 1) and agree >= checked - 3
         for layer in range(2):
-            gk, gv = t.kv_row(layer, 2)
-            assert np.abs(gk.astype(np.float32) - exp["k"][layer, 2].astype(np.float32)).max() < 3e-2
-            assert np.abs(gv.astype(np.float32) - exp["v"][layer, 2].astype(np.float32)).max() < 3e-2
+            for pos in (2, 19):
+                gk, gv = t.kv_row(layer, pos)
+                assert np.abs(gk.astype(np.float32) - exp["k"][layer, pos].astype(np.float32)).max() < 1e-4
+                assert np.abs(gv.astype(np.float32) - exp["v"][layer, pos].astype(np.float32)).max() < 1e-4
         t.close()
     finally:
-        L.q4_set_fusion(1)
+        L.q4_set_fusion(2)

@@ -14,20 +14,25 @@ pytestmark = pytest.mark.gpu
 def models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     out = {}
-    for name in ("tiny", "tiny_gqa", "small", "longk_gqa"):
+    for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120"):
         p = str(d / (name + ".bin"))
         synth.write_model(p, name, seed=7)
         out[name] = p
     return out
 
 
-def _logit_close(gpu, ref):
+# measured worst case per model (tools/measure_tolerances.py, profiles/r02_parity_observed.json): one fp16 ulp of an O(1)
+# logit = 9.8e-4 (longk_gqa, logits up to 2.2: 1.7e-3); the bounds are 3x that
+BOUND = {"tiny": 3e-3, "tiny_gqa": 3e-3, "small": 3e-3, "longk_gqa": 5e-3, "head128": 5e-3, "head128_k5120": 5e-3}
+
+
+def _logit_close(gpu, ref, bound=5e-3):
     gpu, ref = gpu.astype(np.float64), ref.astype(np.float64)
-    return np.abs(gpu - ref) <= 3e-2 * np.maximum(1.0, np.abs(ref))    # SURVEY 8c forward tolerance
+    return np.abs(gpu - ref) <= bound * np.maximum(1.0, np.abs(ref))
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa"])
-@pytest.mark.parametrize("fusion,graphs", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120"])
+@pytest.mark.parametrize("fusion,graphs", [(2, 1), (1, 1), (0, 1), (2, 0), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()
     L.q4_set_fusion(fusion)
@@ -45,7 +50,7 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
             q4.synchronize()
             ref = m.forward(toks[pos], pos)
             got = t.logits()
-            assert _logit_close(got, ref).all(), "pos %d: max |d| %g" % (pos, np.abs(got.astype(np.float32) - ref.astype(np.float32)).max())
+            assert _logit_close(got, ref, BOUND[name]).all(), "pos %d: max |d| %g" % (pos, np.abs(got.astype(np.float32) - ref.astype(np.float32)).max())
             assert t.pos() == pos + 1
             if gen:
                 nxt = t.token(pos + 1)
@@ -57,12 +62,44 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
         for layer in range(t.config.n_layers):
             for pos in (0, steps - 1):
                 gk, gv = t.kv_row(layer, pos)
-                assert _logit_close(gk, rk[layer, pos]).all() and _logit_close(gv, rv[layer, pos]).all(), (layer, pos)
+                assert _logit_close(gk, rk[layer, pos], 3e-3).all() and _logit_close(gv, rv[layer, pos], 3e-3).all(), (layer, pos)
         t.close()
         m.close()
     finally:
-        L.q4_set_fusion(1)
+        L.q4_set_fusion(2)
         L.q4_set_use_graphs(1)
+
+
+@pytest.mark.parametrize("name,steps,checkpoints", [("head128", 1060, (3, 100, 127, 128, 200, 255, 256, 300, 511, 512, 600, 1023, 1024, 1059)),
+                                                     ("head128_k5120", 290, (3, 127, 128, 200, 255, 256, 289))])
+def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name, steps, checkpoints):
+    """Fusion level 2 (QKV -> attention -> o-proj as ONE launch, hand-offs inside the launch) against levels 1 and 0
+    across the sequence-length bins 128 / 256 / 512 (fused forms) and 1024+ (falls back to the launch sequence): the
+    arithmetic is the same device code, so the logits must be IDENTICAL at every checkpoint, the greedy token rings equal,
+    and no bounded spin may have run out."""
+    L = q4.lib()
+    outs = {}
+    try:
+        for fusion in (2, 1, 0):
+            L.q4_set_fusion(fusion)
+            t = q4.Transformer(models[name])
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in checkpoints:
+                    q4.synchronize()
+                    got.append(t.logits().view(np.uint16).copy())
+            q4.check(L.q4_handoff_status(t.state))
+            ring = [int(t.token(i)) for i in range(steps + 1)]
+            outs[fusion] = (got, ring)
+            t.close()
+    finally:
+        L.q4_set_fusion(2)
+    for fusion in (1, 0):
+        assert outs[fusion][1] == outs[2][1], "token ring differs at fusion level %d" % fusion
+        for a, b, pos in zip(outs[fusion][0], outs[2][0], checkpoints):
+            assert np.array_equal(a, b), "logits differ at position %d (fusion %d vs 2)" % (pos, fusion)
 
 
 @pytest.mark.parametrize("name", ["small", "tiny_gqa", "longk_gqa"])
@@ -81,7 +118,7 @@ def test_fused_equals_unfused_bits(q4, models, name):
         q4.synchronize()
         outs.append(t.logits().copy())
         t.close()
-    L.q4_set_fusion(1)
+    L.q4_set_fusion(2)
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
 
 
@@ -112,7 +149,7 @@ def test_perplexity_path(q4, orc, models):
     ppl = t.perplexity_ids(toks)
     glog = t.logits_array(40)
     rlog = np.stack([m.forward(int(toks[i]), i).astype(np.float32) for i in range(40)])
-    assert (np.abs(glog - rlog) <= 3e-2 * np.maximum(1.0, np.abs(rlog))).all()
+    assert (np.abs(glog - rlog) <= 3e-3 * np.maximum(1.0, np.abs(rlog))).all()
     rppl = orc.compute_perplexity(toks[1:41], rlog)
     assert abs(ppl - rppl) <= 5e-3 * rppl, (ppl, rppl)      # perplexity within 0.5 %
     t.close()

@@ -55,6 +55,17 @@ def test_rope(q4, orc, rng, heads, kv_heads, hs, pos):
     assert np.array_equal(gk[untouched], kc[untouched])
 
 
+def _attention_close(got, ref):
+    """fp16 ulps, not a flat tolerance: expf ulps and the summation order over fp16-rounded probabilities move an output
+    by at most a few ulps, except where the weighted sum cancels to ~0 (there: absolute, 3x the measured 6.1e-5).
+    Measured (tools/measure_tolerances.py): <= 3 ulps up to 256 positions, 1.1 % of outputs off by more than one ulp at
+    16 K positions, worst |err| 6.1e-5 on outputs of <= 0.4."""
+    d = f16_ulp_diff(got, ref)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert ((d <= 4) | (err <= 2e-4)).all(), (int(d.max()), float(err.max()))
+    assert (d > 1).mean() <= 0.03, float((d > 1).mean())
+
+
 @pytest.mark.parametrize("heads,kv_mul,hs,pos,seq", [(32, 1, 128, 0, 128), (32, 1, 128, 255, 256), (32, 1, 128, 300, 512),
                                                       (8, 4, 64, 40, 128), (4, 1, 64, 63, 64), (4, 2, 256, 9, 128),
                                                       (8, 1, 32, 20, 128), (32, 1, 128, 2047, 2048),
@@ -71,11 +82,7 @@ def test_attention(q4, orc, rng, heads, kv_mul, hs, pos, seq):
     q4.MultiHeadAttention(do, dq, dk, dv, None, heads, hs, kv_mul, seq, dpos)
     q4.synchronize()
     got = do.get(np.float16, dim)
-    # expf ulps + summation order on fp16-rounded probabilities: allow 2 fp16 ulp, small fraction
-    d = f16_ulp_diff(got, ref)
-    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), (d.max(), err.max())
-    assert (d > 2).mean() < 0.02, (d > 2).mean()
+    _attention_close(got, ref)
 
 
 @pytest.mark.parametrize("pos,seq", [(2047, 2048), (1000, 2048), (100, 1024), (1023, 1024), (4000, 4096)])
@@ -93,8 +100,7 @@ def test_attention_split_context(q4, orc, rng, pos, seq):
     q4.check(q4.lib().q4_multi_head_attention(do.ptr, dq.ptr, dk.ptr, dv.ptr, att.ptr, heads, hs, kv_mul, seq * 2 if seq < 4096 else seq, dpos.ptr))
     q4.synchronize()
     got = do.get(np.float16, dim)
-    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), err.max()
+    _attention_close(got, ref)
 
 
 def test_copy_embedding_and_convert(q4, rng):
@@ -146,5 +152,4 @@ def test_attention_16k_context(q4, orc, rng, with_scratch):
     q4.check(q4.lib().q4_multi_head_attention(do.ptr, dq.ptr, dk.ptr, dv.ptr, att.ptr if att else None, heads, hs, kv_mul, seq, dpos.ptr))
     q4.synchronize()
     got = do.get(np.float16, dim)
-    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64)))).all(), err.max()
+    _attention_close(got, ref)

@@ -25,7 +25,7 @@ def _pack(tmp_path, fmt, seed, cfg):
 
 
 @pytest.mark.parametrize("fmt,seed,gqa", [(1, 11, False), (0, 12, False), (1, 13, True), (0, 14, True)])
-def test_packed_checkpoint_decodes_like_the_restatement(q4, orc, tmp_path, fmt, seed, gqa):
+def test_packed_checkpoint_decodes_like_the_restatement(q4, orc, tmp_path, fmt, seed, gqa, observed):
     cfg = dict(packer_util.CFG, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
                num_key_value_heads=2 if gqa else 8, vocab_size=512, max_position_embeddings=64)
     if gqa:
@@ -39,19 +39,25 @@ def test_packed_checkpoint_decodes_like_the_restatement(q4, orc, tmp_path, fmt, 
     prompt = [1, 17, 300, 45]
     t.reset(prompt)
     toks = list(prompt)
+    worst = 0.0
     for pos in range(8):
         gen = pos >= len(prompt) - 1
         t.run_transformer(gen)
         q4.synchronize()
         ref = m.forward(toks[pos], pos).astype(np.float64)
         got = t.logits().astype(np.float64)
-        # the dump's rms weights are N(0,1) and the embedding N(0,1): logits of O(10); same bound as the synthetic models
-        assert (np.abs(got - ref) <= 6e-3 * np.maximum(1.0, np.abs(ref))).all(), (pos, np.abs(got - ref).max())
+        # the dump's norm weights, embedding AND lm_head are N(0,1): the residual reaches O(50), one fp16 ulp of it (0.03)
+        # times an O(1) classifier weight moves any logit by that much, whatever its own size -- the error scales with
+        # the LARGEST logit. Measured 1.2e-3 of max|logit| (2 fp16 ulps of it); bound = 3x
+        scale = float(np.abs(ref).max())
+        worst = max(worst, float(np.abs(got - ref).max()) / scale)
+        assert np.abs(got - ref).max() <= 3.6e-3 * scale, (pos, np.abs(got - ref).max(), scale)
         if gen:
             toks.append(int(t.token(pos + 1)))
             top2 = np.sort(ref)[-2:]
             if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):
                 assert toks[-1] == int(np.argmax(ref))
+    observed["packed_checkpoint_fmt%d_%s" % (fmt, "gqa" if gqa else "mha")] = {"logits_max_err_over_max_logit": worst}
     t.close()
     m.close()
 
