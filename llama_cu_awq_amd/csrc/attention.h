@@ -37,18 +37,6 @@ struct AttArgs {
     unsigned long long* dbg;     // profiling stamps (profiling build)
 };
 
-// 16-byte load of a row slice that another CU wrote INSIDE this launch: sc1 (served past the L1), through a buffer
-// descriptor so that hipcc's waitcnt pass tracks it like any other load
-__device__ __forceinline__ u32x4 load16_sc1(const q4_half* base, size_t half_index) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(half_index * 2), 0, 16);
-}
-template <bool SC1>
-__device__ __forceinline__ u32x4 load_row16(const q4_half* base, size_t half_index) {
-    if (SC1) return load16_sc1(base, half_index);
-    return *reinterpret_cast<const u32x4*>(base + half_index);
-}
-
 // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
 template <int LPR, int U, int NW, bool FUSED>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
@@ -90,17 +78,34 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     }
     u32x4 qv;
     if (FUSED) {
-        // the head's q / k / v producer blocks of this launch (sc1 stores, drained, one arrival each)
-        if (tid == 0) spin_until(ho.wait + h, ho.wait_target, ho.error);
+        // q and the k / v rows of the current position arrive as granules from the head's QKV blocks of this launch:
+        // head_size/2 = 64 granules per vector, one per lane of wave 0, polled until all three vectors carry the tag
+        // (these 12 lines are polled by this block only)
+        unsigned* hand = reinterpret_cast<unsigned*>(sc + a.lds_scores);     // [3][64] dwords: q, k row, v row of this head
+        if (wave == 0) {
+            const unsigned gi = (unsigned)h * (head_size / 2) + lane;
+            const unsigned per_mat = (unsigned)(a.kv_dim / 2);                // granules per vector (dim == kv_dim here)
+            unsigned i = 0;
+            for (;; i++) {
+                const u32x2v gq = load_granule(ho.sub, gi), gk = load_granule(ho.sub, per_mat + gi), gv = load_granule(ho.sub, 2 * per_mat + gi);
+                const bool ok = gq[1] == ho.tag && gk[1] == ho.tag && gv[1] == ho.tag;
+                if (__all(ok)) { hand[lane] = gq[0]; hand[64 + lane] = gk[0]; hand[128 + lane] = gv[0]; break; }
+                if (i >= POLL_LIMIT) { if (lane == 0) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#ifdef Q4_PROFILING
+            if (ho.stamp && lane == 0) *ho.stamp = wall_clock64();
+#endif
+        }
         __syncthreads();
-        qv = load16_sc1(a.q, (size_t)h * head_size + sub * 8);
+        qv = reinterpret_cast<const u32x4*>(hand)[sub];
         if (size - 1 < group) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int t = wave * R + row + u * stride;
                 if (t == size - 1) {
-                    kv0[u] = load16_sc1(a.key_cache, hoff + (size_t)t * kv_dim);     // wave-uniform base: the descriptor stays in SGPRs
-                    vv0[u] = load16_sc1(a.value_cache, hoff + (size_t)t * kv_dim);
+                    kv0[u] = reinterpret_cast<const u32x4*>(hand + 64)[sub];
+                    vv0[u] = reinterpret_cast<const u32x4*>(hand + 128)[sub];
                 }
             }
         }
@@ -119,7 +124,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
             } else {
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
-                kv[u] = load_row16<FUSED>(a.key_cache, hoff + (size_t)tc * kv_dim);   // (FUSED: may be the row written in this launch)
+                kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
+                if (FUSED && tc == size - 1) kv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 64)[sub];   // this launch's row
             }
         }
 #pragma unroll
@@ -171,7 +177,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
             } else {
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
-                vv[u] = load_row16<FUSED>(a.value_cache, hoff + (size_t)tc * kv_dim);
+                vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+                if (FUSED && tc == size - 1) vv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 128)[sub];
             }
         }
 #pragma unroll
@@ -212,32 +219,25 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     if (!FUSED && a.dbg) ts[5] = __builtin_readcyclecounter();
     __syncthreads();                                                              // barrier 3: output partials
     if (FUSED) {
-        // 16 bytes per thread (head_size / 8 threads of wave 0 .. ), written through for the o-proj blocks of this launch
-        if ((int)tid < head_size / 8) {
-            u32x4 pk;
+        // one granule (two outputs) per thread of wave 0, ONE store instruction per head, validated by its tag on the
+        // o-proj side; the plain copy keeps RunState::xb what the launch sequence leaves there
+        if ((int)tid < head_size / 2) {
+            float s2[2];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float s2[2];
+            for (int k = 0; k < 2; k++) {
+                const int n = tid * 2 + k;
+                float part[NW];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int n = tid * 8 + e * 2 + k;
-                    float part[NW];
+                for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
+                float s = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
-                    float s = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) s += part[w];
-                    s2[k] = s;
-                }
-                const h2 hh = {(f16_t)s2[0], (f16_t)s2[1]};
-                pk[e] = as_u(hh);
+                for (int w = 0; w < NW; w++) s += part[w];
+                s2[k] = s;
             }
-            q4_half* dst = a.output + (size_t)h * head_size + tid * 8;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pk) : "memory");
+            const h2 hh = {(f16_t)s2[0], (f16_t)s2[1]};
+            store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, as_u(hh), ho.tag);
+            *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + tid * 2) = as_u(hh);
         }
-        drain_stores();
-        __syncthreads();            // head_size / 8 may span two waves (head 256 .. 1024): every storing wave has drained
-        if (tid == 0) __hip_atomic_fetch_add(ho.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         for (int n = tid; n < head_size; n += NW * 64) {
             float part[NW];

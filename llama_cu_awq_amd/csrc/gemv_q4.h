@@ -67,36 +67,40 @@ struct GemvArgs {
     int early;                 // waves in the first `early` slots of a SIMD issue their weight loads before the staging ends
 };
 
-// In-launch hand-off (layer_attn.hip: QKV -> attention -> o-proj as ONE launch). ROLE_PRODUCER blocks publish their
-// outputs with write-through (sc1) stores, drain them and bump `signal[...]`; ROLE_CONSUMER blocks put every weight load
-// in flight FIRST, then one lane polls `wait` (relaxed agent-scope loads, s_sleep between polls, bounded) and the block
-// reads its activation vector with sc1 loads. Forms from MI355X_MICROARCH.md ("Valid forms": sc1 payload -> vmcnt(0) ->
-// flag; consumer: relaxed poll -> sc1 loads). ROLE_NONE compiles to the stand-alone kernel, bit for bit.
+// In-launch hand-off (layer_attn.hip: QKV -> attention -> o-proj as ONE launch) with data-tagged granules: a vector
+// crosses CUs as 8-byte {two halves, tag} words, each written by ONE write-through (sc1) store, so a word is either old or
+// complete and carries its own validity -- no flag, no drain, no arrival counter on the producer side (measured: sc1
+// payload -> s_waitcnt vmcnt(0) -> returning atomic cost every producer block 1.7 us at its end). The tag is the launch's
+// epoch (a device word read at entry, bumped by the launch's last block), so stale granules of earlier launches never
+// match. Consumers put their weight loads in flight first, then poll with uncached (sc1) loads, bounded, with s_sleep.
+// Polls must stay off shared lines: an uncached poll lands on the memory channel of its address, and since a wave's loads
+// return in order, 160 blocks polling two shared cache lines stalled every weight stream of the launch (the later QKV
+// blocks ended 4-10 us late, tools/timeline_block.py). Here a line is polled by at most a handful of blocks.
+// (MI355X_MICROARCH.md: "handoff-1to1 ... data-tagged granules", R2.) ROLE_NONE compiles to the stand-alone kernel.
 constexpr int ROLE_NONE = 0, ROLE_PRODUCER = 1, ROLE_CONSUMER = 2;
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 struct Handoff {
-    unsigned* signal;      // producer: word(s) to bump (QKV: one per head, indexed by the block's head)
-    unsigned* wait;        // consumer: word to poll
-    unsigned wait_target;  // consumer: value that means "all producers done"
-    unsigned* done;        // consumer: finished-consumer count; the last one clears every word for the next launch
-    unsigned done_target;
-    unsigned* clear;       // words [0, clear_n) cleared by the last consumer
-    int clear_n;
-    unsigned* error;       // set to 1 when a bounded spin ran out (results are garbage then; the host reports it)
+    unsigned tag;          // this launch's tag (epoch + 1; zeroed buffers never match)
+    u32x2v* pub;           // producer: granule vector(s) to publish into (QKV: [3][N/2]; attention: [dim/2])
+    const u32x2v* sub;     // consumer: granule vector to read (o-proj: the attention output, [K/2])
+    int sentinel;          // consumer: granule polled first (staggered over the blocks: few pollers per line)
+    unsigned* error;       // set to 1 when a bounded poll ran out (results are garbage then; the host reports it)
+    unsigned long long* stamp;   // profiling build: wall clock right after the wait
 };
+constexpr unsigned POLL_LIMIT = 1u << 20;   // ~0.25 us per poll: give up after ~0.3 s instead of hanging the GPU
 
-// bounded spin on a monotonic counter: ~0.1 us per poll, 2^21 polls ~ 0.2 s, then give up loudly instead of hanging the GPU
-__device__ __forceinline__ void spin_until(const unsigned* word, unsigned target, unsigned* error) {
-    for (unsigned i = 0; i < (1u << 21); i++) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    if (error) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void store_granule(u32x2v* p, unsigned data, unsigned tag) {
+    const u32x2v g = {data, tag};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(g) : "memory");
 }
-__device__ __forceinline__ void store_half_sc1(q4_half* p, uint16_t v) {
-    asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((unsigned)v) : "memory");
+__device__ __forceinline__ u32x2v load_granule(const u32x2v* base, unsigned index) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b64(r, index * 8u, 0, 16);   // sc1: served past the L1
 }
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
+__device__ __forceinline__ u32x4 load_granule2(const u32x2v* base, unsigned index) {   // two consecutive granules
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, index * 8u, 0, 16);
+}
 template <int MODE>
 struct ModeTraits { static constexpr int NMAT = (MODE == MODE_FFN) ? 2 : 1; };
 
@@ -215,14 +219,23 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         for (int i = 0; i < TS; i++) {
             const unsigned u = tid + i * blockDim.x;
             const unsigned uc = u < nchunks ? u : nchunks - 1;  // clamped, branch-free
-            if (ROLE == ROLE_CONSUMER) {   // produced inside this launch by other CUs: sc1 load (served past the L1)
-                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.K * 2, 0x00020000);
-                xraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, uc * 16, 0, 16);
-            } else {
-                xraw[i] = reinterpret_cast<const u32x4*>(a.x)[uc];
-            }
+            xraw[i] = reinterpret_cast<const u32x4*>(a.x)[uc];
             if (NORM) wraw[i] = reinterpret_cast<const u32x4*>(a.rms_w)[uc];
         }
+    };
+    // consumer role: x arrives as granules ({2 halves, tag} per 8 bytes, 4 granules per 8-half chunk) written inside this
+    // launch by other CUs. Returns true when every granule of this thread carried the launch's tag.
+    auto load_x_granules = [&]() -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < TS; i++) {
+            const unsigned u = tid + i * blockDim.x;
+            const unsigned uc = u < nchunks ? u : nchunks - 1;
+            const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
+            xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
+            ok = ok && g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag;
+        }
+        return ok;
     };
     if (ROLE != ROLE_CONSUMER) load_x();
 
@@ -329,11 +342,23 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     if (early) {    // give the waves that entered last time to queue their x loads (bits 8+ of a.early, 128-cycle steps)
         for (int i = a.early >> 8; i > 0; i--) __builtin_amdgcn_s_sleep(2);
     }
-    if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers, then fetch x
-        static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
-        if (tid == 0) spin_until(ho.wait, ho.wait_target, ho.error);
+    if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers' granules
+        static_assert(ROLE != ROLE_CONSUMER || (ABL == 5 && !NORM), "consumer role: all loads first");
+        if (tid == 0) {            // one lane polls ONE granule (a different line for neighbouring blocks) ...
+            unsigned i = 0;
+            while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(8);
+            if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
-        load_x();
+        for (unsigned i = 0;; i++) {   // ... then the block reads the whole vector; every granule validates itself
+            const bool ok = load_x_granules();
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            if (i >= POLL_LIMIT / 8) { if (tid == 0) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+#ifdef Q4_PROFILING
+        if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();
+#endif
     }
     if (ABL != 4 && !early) stage_tail();      // (ABL 4: no staging at all, garbage x -- the kernel without the x chain)
     __builtin_amdgcn_sched_barrier(0);
@@ -473,24 +498,27 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
         if (ROLE == ROLE_PRODUCER) {
-            // write-through stores, drained, then ONE arrival per block on the head's counter (all of a block's columns
-            // belong to one head: the launcher checks head_size/2 % (2 * waves) == 0)
-            if (writer && n < N) store_half_sc1(out + n, f2h(r));
-            drain_stores();
+#ifdef Q4_PROFILING
+            if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();     // math done, publishing starts
+#endif
+            // The block's 2 x 16 consecutive halves (its pairs' first and second halves; all of one head: the launcher
+            // checks head_size/2 % (2 * waves) == 0) are gathered in LDS. They go to their ordinary destination (q, the KV
+            // cache row) as plain 16-byte stores, and to the hand-off vector as 16 granules from ONE store instruction.
+            uint16_t* hbuf = reinterpret_cast<uint16_t*>(smem + (size_t)NUNITS * 16 + TS * 512 + (size_t)NUNITS * 4 + 16);
+            const int nwv = blockDim.x >> 6;                 // pairs per block = 2 * nwv
+            if (writer) hbuf[(row >> 1) * (2 * nwv) + wave * 2 + (row & 1)] = f2h(r);
             __syncthreads();
-            if (tid == 0) {
-                const int hb = (int)(vbx * (blockDim.x >> 6) * 2) / hp;
-                __hip_atomic_fetch_add(ho.signal + hb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int p0 = (int)(vbx * nwv * 2);            // first pair of the block
+            const int head0 = p0 / hp, i0 = p0 - head0 * hp;
+            const int e0 = head0 * a.head_size + i0;         // first element of segment 0 in the output vector
+            if ((int)tid < 2 * nwv) {                        // one granule (2 halves) per lane: nwv per segment
+                const int seg = tid / nwv, k = tid - seg * nwv;
+                const unsigned data = *reinterpret_cast<const unsigned*>(hbuf + seg * (2 * nwv) + 2 * k);
+                store_granule(ho.pub + (size_t)mat0 * (N / 2) + (e0 + seg * hp) / 2 + k, data, ho.tag);
+                *reinterpret_cast<unsigned*>(out + e0 + seg * hp + 2 * k) = data;
             }
         } else {
             if (writer && n < N) out[n] = f2h(r);
-        }
-    }
-    if (ROLE == ROLE_CONSUMER) {   // the last consumer block to finish leaves every hand-off word at zero for the next launch
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(ho.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == ho.done_target - 1u)
-                for (int i = 0; i < ho.clear_n; i++) __hip_atomic_store(ho.clear + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (ABL == 3 && a.dbg != nullptr && lane == 0) {

@@ -18,45 +18,64 @@
 namespace q4 {
 
 constexpr int LA_WAVES = 8;          // 512-thread blocks for every role
+int g_la_early = 0;                  // early-bird waves of the QKV role (profiling build: q4_set_gemv_early(4, early))
 
 struct AttBlockArgs {
     GemvArgs qkv;
     GemvArgs oproj;
     AttArgs att;
-    unsigned* sync;                  // [heads] q/k/v arrivals per head, [heads] attention arrivals, [heads+1] finished
-                                     // o-proj blocks, [heads+2] error flag
+    unsigned* sync;                  // hand-off words (sync_layout below), all zero between launches
     unsigned nq, nqx, nheads, no;    // QKV blocks (nqx per matrix), attention blocks, o-proj blocks
-    unsigned qkv_target;             // producer blocks per head: 3 * (head_size/2) / (2 * LA_WAVES)
+    unsigned long long* dbg;         // profiling build: [block][4] wall-clock stamps (entry, after the wait, end, role)
 };
 
 template <int SLOTS, bool HALF, int U>
 __global__ void __launch_bounds__(LA_WAVES * 64) attention_block_kernel(const AttBlockArgs a) {
     const unsigned b = blockIdx.x;
+    // sync layout (words): [0] sticky error flag, [32] epoch; granule vectors (8 bytes each) behind the first 4 KB:
+    // q, k, v of this position ([3][dim/2]), then the attention output ([dim/2])
     Handoff ho = {};
-    ho.error = a.sync + a.nheads + 2;
+    ho.error = a.sync;
+    unsigned* epoch = a.sync + 32;
+    ho.tag = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    u32x2v* g_qkv = reinterpret_cast<u32x2v*>(a.sync + 1024);
+    u32x2v* g_att = g_qkv + 3 * (size_t)(a.qkv.N / 2);
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = (b < a.nq ? 0 : b < a.nq + a.nheads ? 1 : 2) | ((unsigned long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) << 8) |
+                                                                ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32); }
+    ho.stamp = a.dbg ? a.dbg + b * 4 + 1 : nullptr;
+#endif
     if (b < a.nq) {
-        ho.signal = a.sync;
+        ho.pub = g_qkv;
         gemv_q4_body<MODE_QKV, SLOTS, 4, true, 0, 1, HALF, ROLE_PRODUCER>(a.qkv, b % a.nqx, b / a.nqx, ho);
     } else if (b < a.nq + a.nheads) {
-        ho.wait = a.sync;
-        ho.wait_target = a.qkv_target;
-        ho.signal = a.sync + a.nheads;
+        ho.sub = g_qkv;
+        ho.pub = g_att;
         attention_body<16, U, LA_WAVES, true>(a.att, (int)(b - a.nq), ho);
     } else {
-        ho.wait = a.sync + a.nheads;
-        ho.wait_target = a.nheads;
-        ho.done = a.sync + a.nheads + 1;
-        ho.done_target = a.no;
-        ho.clear = a.sync;
-        ho.clear_n = (int)a.nheads + 2;
-        gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, b - a.nq - a.nheads, 0, ho);
+        const unsigned j = b - a.nq - a.nheads;
+        ho.sub = g_att;
+        ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);   // last granule of head j % heads
+        gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
+        // the launch's last block (dispatched last: every block has read the epoch long before it ends) opens the next epoch
+        if (b == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) a.dbg[b * 4 + 2] = wall_clock64();
+#endif
 }
 
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
 
+// words of hand-off state a model needs for this launch: the error + epoch page, then 4 granule vectors of dim/2 x 8 bytes
+size_t attention_block_sync_words(int dim, int n_heads) {
+    (void)n_heads;
+    return 1024 + (size_t)4 * (dim / 2) * 2;
+}
+
 // true when this geometry / sequence-length bin has a fused form: multi-head (dim == kv_dim), head 128, the one-block
 // attention (bins below the split-context threshold), K = dim in 2 slots or 3 with a shared half slot
+
 bool attention_block_supported(int dim, int kv_dim, int head_size, int seq_len_bin, int split_min) {
     const QGeom g = make_geom(dim, dim);
     const bool slots_ok = g.nslots == 2 || (g.nslots == 3 && g.pw4 - 2 * 64 <= 32);
@@ -78,7 +97,7 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
     qa.out[0] = q; qa.out[1] = key_cache; qa.out[2] = value_cache;
     qa.x = x; qa.rms_w = rms_w; qa.pPos = pPos; qa.loff = loff;
     qa.rope = 1; qa.head_size = head_size; qa.rope_theta = rope_theta; qa.rope_table = rope_table;
-    qa.early = 8;                                  // the first 8-wave block on each CU sends its weight loads early
+    qa.early = g_la_early;                         // the first 8-wave block on each CU sends its weight loads early
     // ---- attention role (launch_attention) ----
     a.att = {xb, q, key_cache + loff, value_cache + loff, head_size, 1, dim, pPos,
              (float)(1.0 / sqrt((double)head_size)), seq_len_bin, nullptr};                 // llama2_q4.cu:273
@@ -88,14 +107,16 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
     fill_mat(oa.m[0], wo);
     oa.out[0] = x; oa.x = xb; oa.accum = 1; oa.loff = -1;
     a.sync = sync;
+#ifdef Q4_PROFILING
+    a.dbg = g_dbg;
+#endif
     a.nqx = dim / (LA_WAVES * 4);
     a.nq = 3 * a.nqx;
     a.nheads = n_heads;
     a.no = dim / (LA_WAVES * 4);
-    a.qkv_target = 3 * (head_size / 2) / (2 * LA_WAVES);
     const int TS = g.nslots;
-    const size_t smem_gemv = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
-    const size_t smem_att = (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem_gemv = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16 + 4 * LA_WAVES * 2;   // + the producers' 2 x 16 halves
+    const size_t smem_att = (size_t)(32 + LA_WAVES * head_size + seq_len_bin + 3 * 64) * 4;   // + q / k row / v row of the head
     const size_t smem = smem_gemv > smem_att ? smem_gemv : smem_att;
     const dim3 grid(a.nq + a.nheads + a.no), block(LA_WAVES * 64);
     if (g.nslots == 2) {

@@ -69,13 +69,16 @@ int rope_table_build(float2** out, int seq_len, int head_size, float theta);   /
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                      int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
                      size_t scratch_bytes);
-// QKV -> attention -> o-proj as one launch (layer_attn.hip); `sync`: heads + 3 zeroed words owned by the model
+// QKV -> attention -> o-proj as one launch (layer_attn.hip); `sync`: attention_block_sync_words() zeroed words owned by the model
+size_t attention_block_sync_words(int dim, int n_heads);
 bool attention_block_supported(int dim, int kv_dim, int head_size, int seq_len_bin, int split_min);
 int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cache, q4_half* value_cache, const q4_half* rms_w,
                            const QWeight* wq, const QWeight* wk, const QWeight* wv, const QWeight* wo, int dim, int n_heads,
                            long long loff, const int* pPos, float rope_theta, const float2* rope_table, int seq_len_bin,
                            unsigned* sync);
 extern int g_att_split_min;
+extern int g_la_early;
+extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
                      int dim, int hidden);
 

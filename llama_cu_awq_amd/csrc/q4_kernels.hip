@@ -386,7 +386,11 @@ void q4_set_ablate(int mode) { g_ablate = mode; }
 void q4_set_ksplit(int on) { g_ksplit = on; }
 void q4_set_half_tail(int on) { g_half_tail = on; q4_reset_graphs(); }
 void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att_split_min = min_bin; q4_reset_graphs(); }
-void q4_set_gemv_early(int kind, int slots) { if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots; }
+void q4_set_gemv_early(int kind, int slots) {
+    if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots;
+    if (kind == 4) g_la_early = slots;      // fused attention-block launch: early birds of the QKV role
+    q4_reset_graphs();
+}
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 void q4_set_gemv_tune(int kind, int cols, int waves) {
     if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }

@@ -40,7 +40,7 @@ static std::map<const Transformer*, Slabs> g_slabs;
 // the network entry points take (Config, RunState, TransformerWeights), not the Transformer: tables are found by RunState
 static std::map<const RunState*, const float2*> g_rope_by_state;
 static std::map<const RunState*, unsigned*> g_sync_by_state;
-static std::map<const RunState*, size_t> g_sync_words;   // count per model: n_heads + 2 (the error flag behind them is sticky)
+static std::map<const RunState*, size_t> g_sync_words;   // words per model; word 0 is the sticky error flag
 const float2* rope_table_of(const RunState* s) {
     auto it = g_rope_by_state.find(s);
     return it == g_rope_by_state.end() ? nullptr : it->second;
@@ -318,11 +318,12 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     g_slabs[t] = slabs;
     if (rc) { q4_free_transformer(t); return rc; }
     if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
-    if (hipMalloc((void**)&slabs.sync, (p->n_heads + 3) * sizeof(unsigned)) == hipSuccess) {
-        hipMemset(slabs.sync, 0, (p->n_heads + 3) * sizeof(unsigned));
+    const size_t sync_words = attention_block_sync_words(p->dim, p->n_heads);
+    if (hipMalloc((void**)&slabs.sync, sync_words * sizeof(unsigned)) == hipSuccess) {
+        hipMemset(slabs.sync, 0, sync_words * sizeof(unsigned));
         g_slabs[t] = slabs;
         g_sync_by_state[&t->state] = slabs.sync;
-        g_sync_words[&t->state] = (size_t)p->n_heads + 2;
+        g_sync_words[&t->state] = sync_words;
     } else {
         (void)hipGetLastError();    // no hand-off words: the network runs its five-launch sequence
     }
@@ -603,7 +604,8 @@ int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_toke
     Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
     if (unsigned* sync = sync_words_of(s)) {     // hand-off words are zero between launches; also after a failed one
         auto it = g_sync_words.find(s);
-        Q4_HIP(hipMemsetAsync(sync, 0, (it != g_sync_words.end() ? it->second : 0) * sizeof(unsigned), g_stream));
+        if (it != g_sync_words.end() && it->second > 32)
+            Q4_HIP(hipMemsetAsync(sync + 32, 0, (it->second - 32) * sizeof(unsigned), g_stream));
     }
     Q4_HIP(hipStreamSynchronize(g_stream));
     s->shared_data->pos = 0;                                                       // :462
@@ -620,7 +622,7 @@ int q4_handoff_status(const RunState* s) {
     auto it = g_sync_words.find(s);
     if (!sync || it == g_sync_words.end()) return Q4_OK;
     unsigned flag = 0;
-    Q4_HIP(hipMemcpy(&flag, sync + it->second, sizeof(flag), hipMemcpyDeviceToHost));
+    Q4_HIP(hipMemcpy(&flag, sync, sizeof(flag), hipMemcpyDeviceToHost));
     if (flag) {
         snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 2)");
         return Q4_ERR_HIP;
