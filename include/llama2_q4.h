@@ -210,10 +210,11 @@ int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, 
                           int copyLogits, Sampler* pSampler);
 int q4_wait_pos(const RunState* s, int pos);
 
-/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1: fused kernels (rmsnorm folded into the consumer
- * GEMV, RoPE + KV write in the QKV epilogue: 5 launches/layer); 2 (default): additionally QKV -> attention -> o-proj
+/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1 (default): fused kernels (rmsnorm folded into the
+ * consumer GEMV, RoPE + KV write in the QKV epilogue: 5 launches/layer); 2: additionally QKV -> attention -> o-proj
  * (llama2_q4.cu:300-323) as ONE launch with in-launch hand-offs where the geometry has that form (multi-head, head 128,
- * bins <= 512), 3 launches/layer. All levels produce identical bits. Resets captured graphs. */
+ * bins <= 512), 3 launches/layer -- bit-identical to level 1, measured 0.3-1.5 % slower on MI355X, kept as an
+ * option. Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */

@@ -157,6 +157,7 @@ struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL, int KS, bool HALF, int ROLE>
 __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned vbx, const unsigned vby, const Handoff& ho) {
     static_assert(ROLE == ROLE_NONE || (KS == 1 && ABL != 3), "hand-off roles: no K split, no time stamps");
+    static_assert(ROLE != ROLE_PRODUCER || MODE == MODE_QKV, "producer epilogue: QKV");
     static_assert(!HALF || (KS == 1 && COLS % 2 == 0), "shared half slot: no K split, column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
@@ -224,19 +225,31 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         }
     };
     // consumer role: x arrives as granules ({2 halves, tag} per 8 bytes, 4 granules per 8-half chunk) written inside this
-    // launch by other CUs. Returns true when every granule of this thread carried the launch's tag.
+    // launch by other CUs. Every thread re-reads ITS chunks until they carry the launch's tag (a chunk that is complete is
+    // not read again); false if the bounded retry ran out.
     auto load_x_granules = [&]() -> bool {
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < TS; i++) {
             const unsigned u = tid + i * blockDim.x;
             const unsigned uc = u < nchunks ? u : nchunks - 1;
-            const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
-            xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
-            ok = ok && g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag;
+            for (unsigned tries = 0;; tries++) {
+                const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
+                xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
+                if (g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag) break;
+                if (tries >= POLL_LIMIT / 4) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
         return ok;
     };
+    if (ROLE == ROLE_CONSUMER && NORM) {   // the norm weights do not depend on the producers
+#pragma unroll
+        for (int i = 0; i < TS; i++) {
+            const unsigned u = tid + i * blockDim.x;
+            wraw[i] = reinterpret_cast<const u32x4*>(a.rms_w)[u < nchunks ? u : nchunks - 1];
+        }
+    }
     if (ROLE != ROLE_CONSUMER) load_x();
 
     // ---- 2. weight / zero / scale loads: the first PRE slots go out BEFORE the activation staging (so HBM is
@@ -343,19 +356,15 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         for (int i = a.early >> 8; i > 0; i--) __builtin_amdgcn_s_sleep(2);
     }
     if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers' granules
-        static_assert(ROLE != ROLE_CONSUMER || (ABL == 5 && !NORM), "consumer role: all loads first");
-        if (tid == 0) {            // one lane polls ONE granule (a different line for neighbouring blocks) ...
+        static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
+        if (tid == 0) {            // one lane polls ONE granule (spread over lines: few pollers per line) ...
             unsigned i = 0;
             while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(8);
             if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        for (unsigned i = 0;; i++) {   // ... then the block reads the whole vector; every granule validates itself
-            const bool ok = load_x_granules();
-            if (__syncthreads_and(ok ? 1 : 0)) break;
-            if (i >= POLL_LIMIT / 8) { if (tid == 0) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
+        // ... then the block reads the whole vector; every granule validates itself
+        if (!load_x_granules()) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef Q4_PROFILING
         if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();
 #endif

@@ -18,6 +18,8 @@ int g_ablate = 0;
 int g_ksplit = 1;
 int g_half_tail = 1;
 int g_att_chunk = 256;       // positions per split-attention block (128 or 256)
+int g_att_8wave = 0;         // head 128, bins 256 / 512: 8 waves x 8 loads in flight (1, the fused launch's shape) or 16 waves x 4
+                            // (0: 8 us per token faster stand-alone, tools/sweep_block2.py)
 int g_att_split_min = 1024;  // smallest sequence-length bin that uses the split-context kernels
 unsigned long long* g_dbg = nullptr;
 // early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain). The
@@ -388,6 +390,7 @@ void q4_set_half_tail(int on) { g_half_tail = on; q4_reset_graphs(); }
 void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att_split_min = min_bin; q4_reset_graphs(); }
 void q4_set_gemv_early(int kind, int slots) {
     if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots;
+    if (kind == 6) g_att_8wave = slots;
     if (kind == 4) g_la_early = slots;      // fused attention-block launch: early birds of the QKV role
     q4_reset_graphs();
 }
@@ -511,6 +514,8 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
             if (max_seq_len <= 128) {   // first bin: 8 waves cover the 128 positions in one pass (no clamped duplicate loads,
                                         // cheaper barriers): 7B -n 256 +1 % over the 16-wave block
                 Q4_LAUNCH((attention_kernel<16, 4, 8>), grid, dim3(8 * 64), smem, aa);
+            } else if (max_seq_len <= 512 && g_att_8wave) {   // the shape of the fused launch's attention role (same bits)
+                Q4_LAUNCH((attention_kernel<16, 8, 8>), grid, dim3(8 * 64), smem, aa);
             } else Q4_ATT(16)
             break;
         case 256: Q4_ATT(32) break;

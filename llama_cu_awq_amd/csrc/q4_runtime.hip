@@ -14,7 +14,7 @@
 namespace q4 {
 
 hipStream_t g_stream = nullptr;
-int g_fusion = 2;
+int g_fusion = 1;
 int g_use_graphs = 1;
 int g_quiet = 0;
 char g_last_error[512] = "";
@@ -414,7 +414,7 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
         // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
         const long long loff = (long long)l * p->seq_len * kv_dim;
-        if (g_fusion >= 2 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
+        if (g_fusion == 2 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
             // :300-323 in ONE launch: QKV blocks, attention heads and o-proj blocks hand over inside the launch (layer_attn.hip)
             Q4_UNLESS(7, launch_attention_block(x, s->xb, s->q, s->key_cache, s->value_cache, L->rms_att_weight, &L->wq_q, &L->wq_k,
                                                 &L->wq_v, &L->wq_o, dim, p->n_heads, loff, pPos, p->rope_theta, rope_table,

@@ -26,10 +26,11 @@ def secs(n):
     return min(tr.generate_ids(prompt, n)[3] for _ in range(3))
 
 
-for fusion, early in ((1, 0), (2, 0), (2, 8 | (8 << 8))):
+for fusion, early, att8 in ((1, 0, 0), (1, 0, 1), (2, 8 | (8 << 8), 1), (2, 0, 1)):
     L.q4_set_fusion(fusion)
     L.q4_set_gemv_early(4, early)
+    L.q4_set_gemv_early(6, att8)
     a, b, c = secs(128), secs(256), secs(512)
-    print("fusion %d early %d: bin128 %.4f ms/token, bin256 %.4f ms/token, bin512 %.4f ms/token" % (
-        fusion, early & 255, 1e3 * a / 127, 1e3 * (b - a) / 128, 1e3 * (c - b) / 256), flush=True)
+    print("fusion %d early %d att8 %d: bin128 %.4f ms/token, bin256 %.4f ms/token, bin512 %.4f ms/token" % (
+        fusion, early & 255, att8, 1e3 * a / 127, 1e3 * (b - a) / 128, 1e3 * (c - b) / 256), flush=True)
 tr.close()

@@ -14,6 +14,7 @@ from llama_cu_awq_amd import api, synth   # noqa: E402
 api.use_profiling_build()
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
 upto = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+fusion = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
     synth.write_model(path, model)
@@ -22,6 +23,7 @@ api.check(L.q4_set_device(0))
 s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
+L.q4_set_fusion(fusion)
 tr = api.Transformer(path)
 tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], upto)
 L.q4_set_use_graphs(0)
@@ -41,7 +43,7 @@ for rep in range(3):
     hw = (d[:, 3] >> 8) & 0xFFFF
     xcc = (d[:, 3] >> 32) & 0xF
     cu = ((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15))      # xcc, se, sh, cu
-    if rep == 2:
+    if rep == 2 and fusion == 2:
         q = d[role_of == 0]
         order = np.argsort(q[:, 2])
         qcu = cu[role_of == 0]
@@ -66,7 +68,7 @@ for rep in range(3):
             len(one), np.median([v[0] for v in one]) if one else 0, max([v[0] for v in one]) if one else 0, len(two),
             np.median([min(v) for v in two]) if two else 0, np.median([max(v) for v in two]) if two else 0))
         print("  distinct CUs: qkv %d, attention %d, o-proj %d" % (len(set(qcu.tolist())), len(att_cus), len(set(cu[role_of == 2].tolist()))))
-    for role, name in ((0, "qkv"), (1, "attention"), (2, "o-proj")):
+    for role, name in ((0, "producer"), (1, "attention"), (2, "consumer")):
         r = d[role_of == role]
         if not len(r):
             continue
