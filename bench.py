@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=32, help="decode steps of the CPU restatement timed for cpu_baseline (~0.4 s each at 7B on 16 cores)")
     ap.add_argument("--f64-steps", type=int, default=10, help="positions of the unrounded double forward used as parity yardstick")
     ap.add_argument("--force-dist", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (13B -n 256, 7B -n 2048)")
     ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
     args = ap.parse_args()
 
@@ -156,6 +157,7 @@ def main():
     kernels = {}
     roofline = None
     if rank == 0:
+        tr.reset(PROMPT_IDS)          # the timed kernels address the KV cache at the device position: back to 0 (after -n 2048 it is seq_len)
         for kid, (name, nbytes) in kb.items():
             tr.bench_kernel(kid, 32)   # warm
             avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
@@ -177,10 +179,15 @@ def main():
             in_network[nm] = round(a_, 3)
         in_network[kb[0][0]] = round(net_avg, 3)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC passes need rocprofv3 around the process:
-        if os.path.exists(tpath) and args.model == "7b":              # measured separately, committed with its CSVs
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and args.model == "7b":
+                tj = json.load(open(tpath))
+                tj = tj.get("0", tj)
+                if "traffic_bytes_per_launch" in tj:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % tname
+                    break
         roofline = {"bound": "hbm", "kernel": kb[0][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"], "min_launch_us": round(net_min, 3),
@@ -266,6 +273,26 @@ def main():
                          "(oracle/q4_oracle.c, OpenMP); the reference has no CPU path" % (n_done, n_done - 1, args.model)}
         m.close()
 
+    # ---- BASELINE configs 3 and 4 beside the headline (rank 0, N == 1): 13B -n 256 and 7B -n 2048, same rule ------------
+    extra = None
+    GB_PER_TOKEN = {("7b", 256): 3.695, ("13b", 256): 7.026, ("7b", 2048): 4.164}      # weights + average KV traffic
+    if rank == 0 and world == 1 and not args.no_extra and args.model == "7b" and ntok == 256:
+        extra = {}
+        tr.close()
+        for mname, n in (("7b", 2048), ("13b", 256)):
+            g2 = synth.GEOMETRIES[mname]
+            p2 = os.path.join(args.model_dir, "llama2_q4_synth_%s_seed20240229.bin" % mname)
+            if not (os.path.exists(p2) and os.path.getsize(p2) == synth.model_bytes(g2)):
+                synth.write_model(p2, g2)
+            t2 = api.Transformer(p2, temperature=0.0)
+            t2.generate_ids(PROMPT_IDS, n)                       # warm + graph capture of every bin
+            best = max(t2.generate_ids(PROMPT_IDS, n)[1] for _ in range(2))
+            gb = GB_PER_TOKEN[(mname, n)]
+            extra["llama2_%s_n%d" % (mname, n)] = {"tokens_per_s": round(best, 1), "ms_per_token": round(1000.0 / best, 4), "GB_per_token": gb,
+                                                    "frac_of_8TBps": round(best * gb / HBM_PEAK_GBS, 4)}
+            t2.close()
+        tr = api.Transformer(path, temperature=0.0)
+
     if rank == 0:
         name, cus, mem = api.device_info()
         out = {
@@ -280,7 +307,9 @@ def main():
                        "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "vocab_size": cfg.vocab_size,
                        "parallelism": "replicas x%d (no data-path collective)" % world},
             "ms_per_token": round(1000.0 * elapsed * world / max(total_tokens, 1), 4),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "parity_vs_cpu_restatement": parity,
+            "whole_token": {"GB_per_token": GB_PER_TOKEN.get((args.model, ntok)), "frac_of_8TBps": round(value / max(world, 1) * GB_PER_TOKEN[(args.model, ntok)] / HBM_PEAK_GBS, 4)
+                            if (args.model, ntok) in GB_PER_TOKEN else None},
+            "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extra, "kernels": kernels, "parity_vs_cpu_restatement": parity,
             "device": name, "cus": cus, "load_s": round(t_load, 2), "synth_s": round(t_gen, 2),
             "tok_s_per_generation": [round(x, 1) for x in per_gen],
         }

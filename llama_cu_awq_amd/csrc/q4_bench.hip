@@ -21,7 +21,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
         case 5: return q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f);
         case 6: return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
                                         p->n_heads / p->n_kv_heads, p->seq_len, s->pos, (float*)s->att,
-                                        (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half));
+                                        (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half), nullptr);
         case 7: return q4_rmsnorm(s->xb, s->x, w->rms_final_weight, dim);
         case 8: return q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 0);
         case 9: return q4_copy_embedding(s->x, w->token_embedding_table, dim, s->shared_data->tokens, s->pos);
@@ -35,6 +35,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
 extern "C" double q4_bench_kernel_graph(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
                                         int reps) {
     if (iters < 1 || reps < 1 || !g_stream) return -1.0;
+    if (s->shared_data->pos >= p->seq_len) return -1.0;   // the kernels write the KV row of the device position: it must exist
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal) != hipSuccess) return -1.0;
@@ -60,6 +61,7 @@ extern "C" double q4_bench_kernel_graph(int kernel_id, const Config* p, RunState
 extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, const TransformerWeights* w, int iters,
                                   double* min_us, double* max_us) {
     if (iters < 1 || !p || !s || !w) return -1.0;
+    if (s->shared_data->pos >= p->seq_len) return -1.0;   // the kernels write the KV row of the device position: it must exist
     const int dim = p->dim, hidden = p->hidden_dim;
     const int head_size = dim / p->n_heads;
     const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;

@@ -9,6 +9,7 @@ typedef _Float16 f16_t;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int as_i(float v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ float as_f(int v) { return __builtin_bit_cast(float, v); }

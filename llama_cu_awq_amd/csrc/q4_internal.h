@@ -68,7 +68,7 @@ const float2* rope_table_of(const RunState* s);   // this model's table (q4_runt
 int rope_table_build(float2** out, int seq_len, int head_size, float theta);   // (cos,sin) table for the fused QKV epilogue
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                      int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
-                     size_t scratch_bytes);
+                     size_t scratch_bytes, unsigned* arrive);   // arrive: n_heads zeroed counters (split-context merge by the last block) or null
 // QKV -> attention -> o-proj as one launch (layer_attn.hip); `sync`: attention_block_sync_words() zeroed words owned by the model
 size_t attention_block_sync_words(int dim, int n_heads);
 bool attention_block_supported(int dim, int kv_dim, int head_size, int seq_len_bin, int split_min);

@@ -120,14 +120,73 @@ __global__ void rope_kernel(q4_half* sq, q4_half* sk_base, int num_kv_heads, int
 // MultiHeadAttention: attention_body / attention_kernel live in attention.h (shared with the fused launch, layer_attn.hip)
 // Long contexts: the same block, but one per (head, 256-position chunk) so that all CUs pull on the KV cache (at
 // pos 2047 a layer's K+V is 32 MB; 32 single-head blocks would stream it at a few CUs' worth of bandwidth). Each
-// block leaves flash-decode partials -- running max m, sum l of exp(s - m), un-normalised acc[head_size] in fp32 --
-// in the `att` scratch (RunState::att, the buffer the reference keeps its scores in); attention_combine_kernel merges
-// them: out = sum_s exp(m_s - M) acc_s / sum_s exp(m_s - M) l_s. Scores are still rounded through fp16 (:167);
-// the probabilities stay fp32 here (the reference rounds them to fp16, :400 -- a <= 2^-11 relative difference).
+// block leaves a flash-decode partial -- un-normalised acc[head_size], running max m, sum l of exp(s - m), fp32 -- in the
+// `att` scratch (RunState::att, the buffer the reference keeps its scores in); the partials are merged as
+//     out = sum_s exp(m_s - M) acc_s / sum_s exp(m_s - M) l_s      (fixed order over the chunks).
+// Scores are still rounded through fp16 (:167); the probabilities stay fp32 here (the reference rounds them to fp16,
+// :400 -- a <= 2^-11 relative difference).
+// Two ways to merge: the LAST block of a head to finish does it (arrive != nullptr: partial written through (sc1), drained,
+// one returning arrival on the head's counter; nobody waits for anybody, the last arriver re-arms the counter), or
+// attention_combine_kernel in a second launch (the public q4_multi_head_attention, whose caller owns the scratch).
+constexpr int ATT_REC_PAD = 4;   // a partial record is head_size + 4 floats: acc[head_size], m, l, 2 x pad (16-byte rows)
+
+// merge the nsp partial records of one head for output n. The loads of a batch of 8 chunks go out together (a loop
+// of dependent loads costs one memory latency per chunk: the stand-alone combine kernel spent 4.8 us on 8 chunks that way);
+// the arithmetic is strictly in chunk order, whatever the batching.
+template <bool SC1>
+__device__ __forceinline__ void combine_partials(q4_half* out_head, const float* base, int head_size, int nsp, int n) {
+    const int rec = head_size + ATT_REC_PAD;
+    auto ld = [&](const float* p) -> float {
+        return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    };
+    constexpr int B = 8;
+    float M = -INFINITY, denom = 0.f, num = 0.f;
+    if (nsp <= B) {                      // one round trip: m, l and acc[n] of every chunk
+        float mv[B], lv[B], av[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const float* ps = base + (size_t)(k < nsp ? k : 0) * rec;
+            mv[k] = ld(ps + head_size); lv[k] = ld(ps + head_size + 1); av[k] = ld(ps + n);
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) if (k < nsp) M = fmaxf(M, mv[k]);
+#pragma unroll
+        for (int k = 0; k < B; k++) if (k < nsp) denom += lv[k] * expf(mv[k] - M);
+#pragma unroll
+        for (int k = 0; k < B; k++)
+            if (k < nsp) { const float w = expf(mv[k] - M); num += w > 0.f ? av[k] * w : 0.f; }   // neutral chunks hold no acc
+    } else {
+        for (int s0 = 0; s0 < nsp; s0 += B) {
+            float mv[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) mv[k] = ld(base + (size_t)(s0 + k < nsp ? s0 + k : 0) * rec + head_size);
+#pragma unroll
+            for (int k = 0; k < B; k++) if (s0 + k < nsp) M = fmaxf(M, mv[k]);
+        }
+        for (int s0 = 0; s0 < nsp; s0 += B) {
+            float mv[B], lv[B], av[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const float* ps = base + (size_t)(s0 + k < nsp ? s0 + k : 0) * rec;
+                mv[k] = ld(ps + head_size); lv[k] = ld(ps + head_size + 1); av[k] = ld(ps + n);
+            }
+#pragma unroll
+            for (int k = 0; k < B; k++)
+                if (s0 + k < nsp) {
+                    const float w = expf(mv[k] - M);
+                    denom += lv[k] * w;
+                    num += w > 0.f ? av[k] * w : 0.f;
+                }
+        }
+    }
+    out_head[n] = f2h(num / denom);
+}
+
 template <int LPR, int U>
 __global__ void __launch_bounds__(ATT_NW * 64) attention_split_kernel(float* partials, const q4_half* q, const q4_half* key_cache,
                                                                       const q4_half* value_cache, int head_size, int kv_mul,
-                                                                      int kv_dim, const int* pPos, float alpha) {
+                                                                      int kv_dim, const int* pPos, float alpha, q4_half* output,
+                                                                      unsigned* arrive) {
     constexpr int R = 64 / LPR, NW = ATT_NW;
     constexpr int stride = NW * R;
     constexpr int ATT_CHUNK = stride * U;                    // positions per block = one register-resident group
@@ -135,110 +194,126 @@ __global__ void __launch_bounds__(ATT_NW * 64) attention_split_kernel(float* par
     float* red_max = reinterpret_cast<float*>(smem);
     float* red_sum = red_max + 16;
     float* outp = red_sum + 16;                              // [NW][head_size]
+    __shared__ int is_last;
     const int h = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = tid >> 6;
     const int row = lane / LPR, sub = lane % LPR;
     const int size = *pPos + 1;
     const int t_base = sp * ATT_CHUNK;
-    float* my = partials + ((size_t)h * nsp + sp) * (head_size + 2);
-    if (t_base >= size) {                                    // chunk entirely in the future: neutral partial
-        if (tid == 0) { my[0] = -INFINITY; my[1] = 0.f; }
-        return;
-    }
-    const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-    const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-    // non-temporal: at these contexts the KV cache (>= 0.5 GB per token) does not stay in the 256 MB Infinity Cache;
-    // the one-block kernel for short contexts keeps the default policy (its 128 MB per token does: 4.1 vs 4.6 us)
-    u32x4 kv[U], vv[U];
+    const int rec = head_size + ATT_REC_PAD;
+    float* my = partials + ((size_t)h * nsp + sp) * rec;
+    const bool live = t_base < size;                         // chunk entirely in the future: neutral partial (m = -inf, l = 0)
+    if (live) {
+        const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+        const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
+        // non-temporal: at these contexts the KV cache (>= 0.5 GB per token) does not stay in the 256 MB Infinity Cache;
+        // the one-block kernel for short contexts keeps the default policy (its 128 MB per token does: 4.1 vs 4.6 us)
+        u32x4 kv[U], vv[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int t = t_base + wave * R + row + u * stride;
-        const int tc = t < size ? t : size - 1;
-        kv[u] = ld_nt(reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim));
-        vv[u] = ld_nt(reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim));
-    }
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
-    float sc[U];
-    float wmax = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int t = t_base + wave * R + row + u * stride;
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
-        s = row_sum<LPR>(s);
-        s = round_h(s * alpha);
-        sc[u] = t < size ? s : -INFINITY;
-        wmax = fmaxf(wmax, sc[u]);
-    }
-    wmax = wave_max(wmax);
-    if (lane == 0) red_max[wave] = wmax;
-    __syncthreads();
-    const float m = row16_max(red_max[lane & 15]);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    float lsum = 0.f;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const float p = expf(sc[u] - m);                     // 0 for masked positions (sc = -inf)
-        if (sub == 0) lsum += p;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const h2 v2 = as_h2(vv[u][e]);
-            acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);
-            acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+        for (int u = 0; u < U; u++) {
+            const int t = t_base + wave * R + row + u * stride;
+            const int tc = t < size ? t : size - 1;
+            kv[u] = ld_nt(reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim));
+            vv[u] = ld_nt(reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim));
         }
-    }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red_sum[wave] = lsum;
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
+        float sc[U];
+        float wmax = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float v = acc[e];
-        if (LPR <= 32) v += __shfl_xor(v, 32);
-        if (LPR <= 16) v += __shfl_xor(v, 16);
-        if (LPR <= 8) v += __shfl_xor(v, 8);
-        if (LPR <= 4) v += __shfl_xor(v, 4);
-        acc[e] = v;
-    }
-    if (lane < LPR) {
+        for (int u = 0; u < U; u++) {
+            const int t = t_base + wave * R + row + u * stride;
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
+            s = row_sum<LPR>(s);
+            s = round_h(s * alpha);
+            sc[u] = t < size ? s : -INFINITY;
+            wmax = fmaxf(wmax, sc[u]);
+        }
+        wmax = wave_max(wmax);
+        if (lane == 0) red_max[wave] = wmax;
+        __syncthreads();
+        const float m = row16_max(red_max[lane & 15]);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float p = expf(sc[u] - m);                     // 0 for masked positions (sc = -inf)
+            if (sub == 0) lsum += p;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const h2 v2 = as_h2(vv[u][e]);
+                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);
+                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+            }
+        }
+        lsum = wave_sum(lsum);
+        if (lane == 0) red_sum[wave] = lsum;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float v = acc[e];
+            if (LPR <= 32) v += __shfl_xor(v, 32);
+            if (LPR <= 16) v += __shfl_xor(v, 16);
+            if (LPR <= 8) v += __shfl_xor(v, 8);
+            if (LPR <= 4) v += __shfl_xor(v, 4);
+            acc[e] = v;
+        }
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+        }
+        __syncthreads();
+        const float l = row16_sum(red_sum[lane & 15]);
+        // the record leaves as 16-byte stores: thread n4 sums the NW wave partials of outputs 4*n4 .. 4*n4+3
+        if ((int)tid <= head_size / 4) {
+            f32x4 r4;
+            if ((int)tid < head_size / 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int n = tid * 4 + k;
+                    float part[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) s += part[w];
+                    r4[k] = s;
+                }
+            } else {
+                r4 = (f32x4){m, l, 0.f, 0.f};
+            }
+            float* dst = my + tid * 4;
+            if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
+            else *reinterpret_cast<f32x4*>(dst) = r4;
+        }
+    } else if (tid == 0) {
+        const f32x4 r4 = {-INFINITY, 0.f, 0.f, 0.f};
+        float* dst = my + head_size;
+        if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
+        else *reinterpret_cast<f32x4*>(dst) = r4;
+    }
+    if (arrive == nullptr) return;
+    // ---- last-arriver merge: record drained to memory, then ONE returning arrival per block ------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (unsigned)nsp - 1u;
+        if (is_last) __hip_atomic_store(arrive + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
     }
     __syncthreads();
-    const float l = row16_sum(red_sum[lane & 15]);
-    if (tid == 0) { my[0] = m; my[1] = l; }
-    for (int n = tid; n < head_size; n += NW * 64) {
-        float part[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; w++) s += part[w];
-        my[2 + n] = s;
-    }
+    if (!is_last) return;
+    for (int n = tid; n < head_size; n += NW * 64)
+        combine_partials<true>(output + (size_t)h * head_size, partials + (size_t)h * nsp * rec, head_size, nsp, n);
 }
 
 __global__ void attention_combine_kernel(q4_half* output, const float* partials, int head_size, int nsp) {
     const int h = blockIdx.x;
-    const float* base = partials + (size_t)h * nsp * (head_size + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsp; s++) M = fmaxf(M, base[(size_t)s * (head_size + 2)]);
-    float denom = 0.f;
-    for (int s = 0; s < nsp; s++) {
-        const float* ps = base + (size_t)s * (head_size + 2);
-        denom += ps[1] * expf(ps[0] - M);                   // fixed order over chunks
-    }
-    for (int n = threadIdx.x; n < head_size; n += blockDim.x) {
-        float num = 0.f;
-        for (int s = 0; s < nsp; s++) {
-            const float* ps = base + (size_t)s * (head_size + 2);
-            const float w = expf(ps[0] - M);
-            num += w > 0.f ? ps[2 + n] * w : 0.f;           // neutral chunks hold no acc
-        }
-        output[(size_t)h * head_size + n] = f2h(num / denom);
-    }
+    for (int n = threadIdx.x; n < head_size; n += blockDim.x)
+        combine_partials<false>(output + (size_t)h * head_size, partials + (size_t)h * nsp * (head_size + ATT_REC_PAD), head_size, nsp, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -470,25 +545,29 @@ int q4_rope_rotation(q4_half* q, q4_half* k, int num_heads, int num_kv_heads, in
 namespace q4 {
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                      int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
-                     size_t scratch_bytes) {
+                     size_t scratch_bytes, unsigned* arrive) {
     const int dim = head_size * num_heads;
     const int kv_dim = dim / kv_mul;
     const float alpha = (float)(1.0 / sqrt((double)head_size));                     // llama2_q4.cu:273
     dim3 block(ATT_NW * 64);
-    // long context: one block per (head, 256-position chunk) + a combine kernel (see attention_split_kernel)
-    const int chunk = g_att_chunk == 128 ? 128 : 256;
+    // long context: one block per (head, 256-position chunk); merged by each head's last block (arrive != nullptr: the
+    // model's counters) or by a second launch (see attention_split_kernel)
+    const int chunk = g_att_chunk == 128 && head_size == 128 ? 128 : 256;
     const int nsp = divUp(max_seq_len, chunk);
-    const bool split = max_seq_len >= g_att_split_min && scratch != nullptr && head_size == 128 &&
-                       (size_t)num_heads * nsp * (head_size + 2) * sizeof(float) <= scratch_bytes;
+    const bool split = max_seq_len >= g_att_split_min && scratch != nullptr && (head_size == 64 || head_size == 128 || head_size == 256) &&
+                       (size_t)num_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
     if (split) {
         const size_t smem = (size_t)(32 + ATT_NW * head_size) * 4;
-        if (chunk == 128)
-            Q4_LAUNCH((attention_split_kernel<16, 2>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
-                      head_size, kv_mul, kv_dim, pPos, alpha);
-        else
-            Q4_LAUNCH((attention_split_kernel<16, 4>), dim3(num_heads, nsp), block, smem, scratch, q, key_cache, value_cache,
-                      head_size, kv_mul, kv_dim, pPos, alpha);
-        Q4_LAUNCH(attention_combine_kernel, dim3(num_heads), dim3(128), 0, output, (const float*)scratch, head_size, nsp);
+        const dim3 grid(num_heads, nsp);
+#define Q4_SPLIT(L, UU) Q4_LAUNCH((attention_split_kernel<L, UU>), grid, block, smem, scratch, q, key_cache, value_cache, head_size, \
+                                  kv_mul, kv_dim, pPos, alpha, output, arrive)
+        if (head_size == 64) Q4_SPLIT(8, 2);                 // 16 waves x 8 rows x 2 = 256 positions per block
+        else if (head_size == 256) Q4_SPLIT(32, 8);          // 16 x 2 x 8
+        else if (chunk == 128) Q4_SPLIT(16, 2);
+        else Q4_SPLIT(16, 4);
+#undef Q4_SPLIT
+        if (arrive == nullptr)
+            Q4_LAUNCH(attention_combine_kernel, dim3(num_heads), dim3(128), 0, output, (const float*)scratch, head_size, nsp);
         Q4_LAUNCH_CHECK();
         return Q4_OK;
     }
@@ -534,7 +613,7 @@ int q4_multi_head_attention(q4_half* output, const q4_half* q, const q4_half* ke
     // `att` (n_heads * max_seq_len halves in the reference) doubles as the split-context scratch when it is big enough
     const size_t att_bytes = att ? (size_t)num_heads * max_seq_len * sizeof(q4_half) : 0;
     return launch_attention(output, q, key_cache, value_cache, num_heads, head_size, kv_mul, max_seq_len, pPos, (float*)att,
-                            att_bytes);
+                            att_bytes, nullptr);       // the caller owns `att`: no counters in it, merged by a second launch
 }
 
 int q4_copy_embedding(q4_half* x, const q4_half* table, int size, const int* tokens, const int* pPos) {

@@ -437,7 +437,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
         }
         Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
                                       seq_len_bin, pPos, (float*)s->att,
-                                      (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half)));   // :320
+                                      (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half),
+                                      sync && p->n_heads <= 512 ? sync + 128 : nullptr));              // :320
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
         }
         if (g_fusion) {

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     out = {}
-    for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120"):
+    for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head64_long"):
         p = str(d / (name + ".bin"))
         synth.write_model(p, name, seed=7)
         out[name] = p
@@ -123,6 +123,43 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
         assert np.array_equal(a, b), "logits differ at position %d (fusion 0 vs 1)" % pos
     if name != "head128_k5120":
         assert outs[0][1] == outs[1][1], "token ring differs at fusion level 0"
+
+
+@pytest.mark.parametrize("name,target", [("head128", 1050), ("head64_long", 1100), ("head64_long", 1290)])
+def test_split_context_merge_by_the_last_block(q4, orc, models, name, target):
+    """Bins >= 1024 inside the network: one attention block per (head, 256 positions), merged by each head's LAST block
+    (returning arrival on the model's counters, no second launch). Decode `target` positions through the captured graphs,
+    hand the GPU's KV cache to the restatement and compare ONE step from the identical state (head 128, and head 64 with
+    grouped-query attention)."""
+    import ctypes as C
+    L = q4.lib()
+    t = q4.Transformer(models[name])
+    m = orc.Model(models[name])
+    toks, tps, timed, _ = t.generate_ids([1, 5, 9], target)
+    assert t.pos() == target
+    cfg = t.config
+    n = cfg.n_layers * cfg.seq_len * (cfg.dim * cfg.n_kv_heads // cfg.n_heads)
+    k = np.empty(n, dtype=np.uint16)
+    v = np.empty(n, dtype=np.uint16)
+    q4.check(L.q4_memcpy_d2h(k.ctypes.data, t.state.contents.key_cache, k.nbytes))
+    q4.check(L.q4_memcpy_d2h(v.ctypes.data, t.state.contents.value_cache, v.nbytes))
+    np.ctypeslib.as_array(m.L.orc_key_cache(m.h), shape=(n,))[:] = k
+    np.ctypeslib.as_array(m.L.orc_value_cache(m.h), shape=(n,))[:] = v
+    tok = int(t.token(target))
+    for rep in range(3):                                   # three consecutive steps: the counters re-arm themselves
+        t.run_transformer(True)
+        q4.synchronize()
+        got = t.logits()
+        ref = m.forward(tok, target + rep)
+        assert _logit_close(got, ref, 5e-3).all(), (rep, np.abs(got.astype(np.float32) - ref.astype(np.float32)).max())
+        tok = int(t.token(target + rep + 1))
+        top2 = np.sort(ref.astype(np.float32))[-2:]
+        if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):
+            assert tok == int(np.argmax(ref.astype(np.float32)))
+        else:
+            break
+    t.close()
+    m.close()
 
 
 @pytest.mark.parametrize("name", ["small", "tiny_gqa", "longk_gqa"])

@@ -55,7 +55,7 @@ def test_rope(q4, orc, rng, heads, kv_heads, hs, pos):
     assert np.array_equal(gk[untouched], kc[untouched])
 
 
-def _attention_close(got, ref):
+def _attention_close(got, ref, frac_gt1=0.03):
     """fp16 ulps, not a flat tolerance: expf ulps and the summation order over fp16-rounded probabilities move an output
     by at most a few ulps, except where the weighted sum cancels to ~0 (there: absolute, 3x the measured 6.1e-5).
     Measured (tools/measure_tolerances.py): <= 3 ulps up to 256 positions, 1.1 % of outputs off by more than one ulp at
@@ -63,7 +63,7 @@ def _attention_close(got, ref):
     d = f16_ulp_diff(got, ref)
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     assert ((d <= 4) | (err <= 2e-4)).all(), (int(d.max()), float(err.max()))
-    assert (d > 1).mean() <= 0.03, float((d > 1).mean())
+    assert (d > 1).mean() <= frac_gt1, float((d > 1).mean())
 
 
 @pytest.mark.parametrize("heads,kv_mul,hs,pos,seq", [(32, 1, 128, 0, 128), (32, 1, 128, 255, 256), (32, 1, 128, 300, 512),
@@ -85,14 +85,16 @@ def test_attention(q4, orc, rng, heads, kv_mul, hs, pos, seq):
     _attention_close(got, ref)
 
 
+@pytest.mark.parametrize("hs,kv_mul", [(128, 1), (64, 1), (64, 4), (256, 2)])
 @pytest.mark.parametrize("pos,seq", [(2047, 2048), (1000, 2048), (100, 1024), (1023, 1024), (4000, 4096)])
-def test_attention_split_context(q4, orc, rng, pos, seq):
-    """Long-context path: one block per (head, 256-position chunk) + combine, scratch = the `att` buffer."""
-    heads, hs, kv_mul = 32, 128, 1
+def test_attention_split_context(q4, orc, rng, pos, seq, hs, kv_mul):
+    """Long-context path: one block per (head, 256-position chunk) + combine, scratch = the `att` buffer; head sizes 64,
+    128 and 256, with grouped-query attention."""
+    heads = 4096 // hs if hs != 256 else 8
     dim = heads * hs
     q = rng.standard_normal(dim).astype(np.float16)
-    kc = rng.standard_normal(seq * dim).astype(np.float16)
-    vc = rng.standard_normal(seq * dim).astype(np.float16)
+    kc = rng.standard_normal(seq * dim // kv_mul).astype(np.float16)
+    vc = rng.standard_normal(seq * dim // kv_mul).astype(np.float16)
     ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos)
     dq, dk, dv, do = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(vc), q4.DevBuf(nbytes=dim * 2)
     att = q4.DevBuf(nbytes=heads * max(seq, dim) * 2 * 2)
@@ -100,7 +102,10 @@ def test_attention_split_context(q4, orc, rng, pos, seq):
     q4.check(q4.lib().q4_multi_head_attention(do.ptr, dq.ptr, dk.ptr, dv.ptr, att.ptr, heads, hs, kv_mul, seq * 2 if seq < 4096 else seq, dpos.ptr))
     q4.synchronize()
     got = do.get(np.float16, dim)
-    _attention_close(got, ref)
+    # the split form keeps the probabilities in fp32 where the reference's `att` buffer rounds them to fp16 (:400): up to
+    # 2^-11 relative per term, which moves ~13 % of these tiny (|out| ~ 0.03) outputs by 2 fp16 ulps (measured); the
+    # absolute bound is the same as for the one-block kernel
+    _attention_close(got, ref, frac_gt1=0.25)
 
 
 def test_copy_embedding_and_convert(q4, rng):
