@@ -17,10 +17,10 @@ enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUN
 int g_ablate = 0;
 int g_ksplit = 1;
 int g_half_tail = 1;
-int g_att_chunk = 256;       // positions per split-attention block (128 or 256)
+int g_att_chunk = 0;         // positions per split-attention block: 128, 256, or 0 = 128 up to bin 512 and 256 above (measured)
 int g_att_8wave = 0;         // head 128, bins 256 / 512: 8 waves x 8 loads in flight (1, the fused launch's shape) or 16 waves x 4
                             // (0: 8 us per token faster stand-alone, tools/sweep_block2.py)
-int g_att_split_min = 1024;  // smallest sequence-length bin that uses the split-context kernels
+int g_att_split_min = 512;   // smallest sequence-length bin that uses the split-context kernels
 unsigned long long* g_dbg = nullptr;
 // early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain). The
 // hold-back before the early loads (bits 8+, 128-cycle steps) is chosen per launch in launch_one(): with 21 waves per CU
@@ -552,7 +552,8 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     dim3 block(ATT_NW * 64);
     // long context: one block per (head, 256-position chunk); merged by each head's last block (arrive != nullptr: the
     // model's counters) or by a second launch (see attention_split_kernel)
-    const int chunk = g_att_chunk == 128 && head_size == 128 ? 128 : 256;
+    const int want = g_att_chunk ? g_att_chunk : (max_seq_len <= 512 ? 128 : 256);
+    const int chunk = want == 128 && head_size == 128 ? 128 : 256;
     const int nsp = divUp(max_seq_len, chunk);
     const bool split = max_seq_len >= g_att_split_min && scratch != nullptr && (head_size == 64 || head_size == 128 || head_size == 256) &&
                        (size_t)num_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
