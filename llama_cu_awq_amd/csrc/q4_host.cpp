@@ -172,10 +172,16 @@ double q4_generate(Transformer* transformer, struct Tokenizer* tokenizer, Sample
     int pos = 0;
     RunState* state = &transformer->state;
     die_on(q4_reset_sequence(state, prompt_tokens, num_prompt_tokens));            // :461-463
+    int queued = 0;
     while (pos < steps) {
         // step `pos` is queued behind step pos-1 before the host waits for step pos-1's token (reference: sync, then
-        // launch, :468-470) -- same device order, the GPU never idles between tokens
-        die_on(q4_run_transformer_at(pos, pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
+        // launch, :468-470) -- same device order, the GPU never idles between tokens; greedy steps inside one bin go out
+        // Q4_MULTI_STEPS at a time
+        if (pos >= queued) {
+            const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &transformer->config, sampler);
+            die_on(q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
+            queued = pos + k;
+        }
         die_on(q4_wait_pos(state, pos));                                           // :468
         if (pos > 0) {
             next = q4_shared_token(state, pos);                                    // output token of the previous iteration

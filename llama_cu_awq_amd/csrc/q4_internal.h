@@ -78,6 +78,7 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
                            unsigned* sync);
 extern int g_att_split_min;
 extern int g_la_early;
+extern int g_multi_steps;
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
                      int dim, int hidden);

@@ -466,6 +466,7 @@ void q4_set_attention_split(int chunk, int min_bin) { g_att_chunk = chunk; g_att
 void q4_set_gemv_early(int kind, int slots) {
     if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots;
     if (kind == 6) g_att_8wave = slots;
+    if (kind == 7) g_multi_steps = slots;
     if (kind == 4) g_la_early = slots;      // fused attention-block launch: early birds of the QKV role
     q4_reset_graphs();
 }

@@ -15,6 +15,7 @@ namespace q4 {
 
 hipStream_t g_stream = nullptr;
 int g_fusion = 1;
+int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
 char g_last_error[512] = "";
@@ -51,8 +52,8 @@ static unsigned* sync_words_of(const RunState* s) {
 }
 
 // graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
-static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][8];
-static bool g_captured[Q4_MAX_GRAPHS][8];
+static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][16];   // [bin][variant | 8: Q4_MULTI_STEPS steps per graph]
+static bool g_captured[Q4_MAX_GRAPHS][16];
 static const void* g_graph_owner = nullptr;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -130,7 +131,7 @@ void q4_set_quiet(int quiet) { g_quiet = quiet; }
 
 void q4_reset_graphs(void) {
     for (int i = 0; i < Q4_MAX_GRAPHS; i++)
-        for (int v = 0; v < 8; v++)
+        for (int v = 0; v < 16; v++)
             if (g_captured[i][v]) {
                 hipGraphExecDestroy(g_graphs[i][v]);
                 g_captured[i][v] = false;
@@ -563,28 +564,48 @@ int q4_run_transformer(int gen_token, const Config* p, RunState* s, const Transf
 // The same step with the position supplied by the caller instead of read back from SharedData::pos: the device keeps
 // its own position (`s->pos`) and reads its input token from the ring, so step pos+1 can be queued while step pos is
 // still running (generate() below); only the graph bin depends on the host's idea of the position.
-int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
-                          Sampler* pSampler) {
-    const int seq_len = pos + 1;                                                   // :354
-    const bool greedy = sampler_is_greedy(pSampler, gen_token);
+static int graph_bin(int seq_len, const Config* p, int* seq_len_bin_out) {
     int graphIndex;
     int seq_len_bin = 128;
     for (graphIndex = 0; graphIndex < Q4_MAX_GRAPHS - 1; seq_len_bin *= 2, graphIndex++)
         if (seq_len <= seq_len_bin) break;                                         // :356-359
     if ((seq_len > seq_len_bin) || (graphIndex == Q4_MAX_GRAPHS - 1)) seq_len_bin = p->seq_len;   // :360
+    *seq_len_bin_out = seq_len_bin;
+    return graphIndex;
+}
+
+int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, const TransformerWeights* w, int copyLogits,
+                          Sampler* pSampler) {
+    return q4_run_transformer_steps(pos, 1, gen_token, p, s, w, copyLogits, pSampler);
+}
+
+// `nsteps` consecutive greedy steps (positions pos .. pos + nsteps - 1, same gen_token) as ONE graph replay: the device
+// advances its own position and feeds itself the tokens (argmax_kernel writes the ring, copy_embedding reads it), so a
+// replay needs nothing from the host between steps -- the per-replay launch cost is paid once per nsteps tokens. Only
+// nsteps == 1 or Q4_MULTI_STEPS are captured; the caller keeps a group inside one sequence-length bin (q4_steps_that_fit).
+int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p, RunState* s, const TransformerWeights* w,
+                             int copyLogits, Sampler* pSampler) {
+    const int seq_len = pos + nsteps;                                              // :354 (of the group's last step)
+    const bool greedy = sampler_is_greedy(pSampler, gen_token);
+    int seq_len_bin;
+    const int graphIndex = graph_bin(seq_len, p, &seq_len_bin);
+    if (nsteps != 1 && (nsteps != g_multi_steps || !greedy || !g_use_graphs)) return Q4_ERR_ARG;
 
     if (g_use_graphs) {
         if (g_graph_owner != (const void*)s) { q4_reset_graphs(); g_graph_owner = s; }
         // Unlike the reference, the greedy sampler kernel and the fp32 logits copy are part of the captured
         // graph (one launch per token instead of up to three); the variant index keeps them apart.
-        const int variant = (gen_token ? 1 : 0) | (copyLogits ? 2 : 0) | (greedy ? 0 : 4);
+        const int variant = (gen_token ? 1 : 0) | (copyLogits ? 2 : 0) | (greedy ? 0 : 4) | (nsteps > 1 ? 8 : 0);
         if (!g_captured[graphIndex][variant]) {                                    // :362-371
             hipGraph_t graph = nullptr;
             Q4_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
-            int rc = q4_run_llama_network(s->pos, p, s, w, seq_len_bin);
-            if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
-            if (!rc && greedy)
-                rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+            int rc = 0;
+            for (int i = 0; i < nsteps && !rc; i++) {
+                rc = q4_run_llama_network(s->pos, p, s, w, seq_len_bin);
+                if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
+                if (!rc && greedy)
+                    rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+            }
             hipError_t e = hipStreamEndCapture(g_stream, &graph);
             if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
             Q4_HIP(e);
@@ -593,7 +614,9 @@ int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, 
             g_captured[graphIndex][variant] = true;
         }
         Q4_HIP(hipGraphLaunch(g_graphs[graphIndex][variant], g_stream));          // :372
-        return sample_impl(pSampler, s, gen_token, false);                         // :384 (argmax already in the graph)
+        int rc = Q4_OK;
+        for (int i = 0; i < nsteps && !rc; i++) rc = sample_impl(pSampler, s, gen_token, false);   // :384 (argmax is in the graph;
+        return rc;                                                                 //  the RNG still advances once per step, P8)
     }
     Q4_TRY(q4_run_llama_network(s->pos, p, s, w, seq_len));                       // :374
     if (copyLogits) Q4_TRY(q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos));   // :377-382
@@ -615,6 +638,20 @@ int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_toke
     return Q4_OK;
 }
 int q4_shared_pos(const RunState* s) { return s->shared_data->pos; }
+
+// How many steps a token loop may queue at once from `pos`: Q4_MULTI_STEPS when graphs are on, the sampler is greedy, the
+// whole group generates (or the whole group feeds prompt tokens), ends by `steps` and stays inside one sequence-length
+// bin; else 1.
+int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p, const Sampler* sampler) {
+    const int k = g_multi_steps;
+    if (k <= 1 || !g_use_graphs || pos + k > steps || pos + k > p->seq_len) return 1;
+    const bool gen0 = pos >= num_prompt_tokens - 1, gen1 = pos + k - 1 >= num_prompt_tokens - 1;
+    if (gen0 != gen1) return 1;
+    if (gen0 && sampler->temperature != 0.0f) return 1;
+    int b0, b1;
+    if (graph_bin(pos + 1, p, &b0) != graph_bin(pos + k, p, &b1)) return 1;
+    return k;
+}
 // The in-launch hand-offs of fusion level 2 spin for a bounded time; a spin that ran out sets a sticky device flag
 // (results from then on are invalid). Synchronises the stream and reports it.
 int q4_handoff_status(const RunState* s) {
@@ -677,12 +714,18 @@ double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_token
     if (steps <= 0 || steps > t->config.seq_len) steps = t->config.seq_len;        // :690
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    int pos = 0;
+    int pos = 0, queued = 0;
     if (q4_reset_sequence(&t->state, prompt_tokens, num_prompt_tokens)) return -1.0;
     while (pos < steps) {
         // the reference synchronises and then launches step `pos` (:468-470); here the launch goes out first, queued
-        // behind step pos-1, and the host then waits for step pos-1's token -- same device order, no idle gap per token
-        if (q4_run_transformer_at(pos, pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+        // behind step pos-1, and the host then waits for step pos-1's token -- same device order, no idle gap per token.
+        // Greedy steps inside one bin go out Q4_MULTI_STEPS at a time (one graph replay); a stop at EOS leaves at most
+        // Q4_MULTI_STEPS - 1 surplus steps behind, which the next q4_reset_sequence discards.
+        if (pos >= queued) {
+            const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &t->config, sampler);
+            if (q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+            queued = pos + k;
+        }
         if (q4_wait_pos(&t->state, pos)) return -1.0;                              // :468
         if (pos > 0) {
             int next = t->state.shared_data->tokens[pos];                          // :473
