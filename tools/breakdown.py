@@ -8,13 +8,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama_cu_awq_amd import api, synth   # noqa: E402
 
+api.use_profiling_build()   # the measurement knobs live in libllama2_q4_prof.so only
+
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
     synth.write_model(path, model)
 L = api.lib()
-L.q4_set_skip_mask.argtypes = [C.c_int]
-L.q4_set_skip_mask.restype = None
 api.check(L.q4_set_device(0))
 s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))

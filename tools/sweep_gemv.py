@@ -7,6 +7,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama_cu_awq_amd import api, synth   # noqa: E402
+
+api.use_profiling_build()   # the measurement knobs live in libllama2_q4_prof.so only
 import bench                               # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
@@ -32,7 +34,6 @@ def run(kid, iters=192):
     return g, avg, nbytes / g / 1e3
 
 
-L.q4_set_ksplit.argtypes = [C.c_int]
 for ks in (1, 0):
     L.q4_set_ksplit(ks)
     for kid in (1, 2, 4):

@@ -7,12 +7,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama_cu_awq_amd import api, synth   # noqa: E402
 
+api.use_profiling_build()   # the measurement knobs live in libllama2_q4_prof.so only
+
 path = "/tmp/llama2_q4_synth_7b_seed20240229.bin"
 if not os.path.exists(path):
     synth.write_model(path, "7b")
 L = api.lib()
-L.q4_set_gemv_early.argtypes = [C.c_int, C.c_int]
-L.q4_set_ksplit.argtypes = [C.c_int]
 api.check(L.q4_set_device(0))
 s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))

@@ -12,9 +12,7 @@ s = C.c_void_p(); api.check(L.q4_stream_create(C.byref(s))); L.q4_set_stream(s)
 tr = api.Transformer(path)
 nw = 11008 // 2
 dbg = api.DevBuf(nbytes=nw * 8 * 8 + 4096)
-L.q4_set_debug_buffer.argtypes = [C.c_void_p]; L.q4_set_debug_buffer(dbg.ptr)
 L.q4_set_gemv_tune(3, 2, 4)
-L.q4_set_gemv_early.argtypes = [C.c_int, C.c_int]
 L.q4_set_gemv_early(3, int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 L.q4_set_ablate(3)
 tr.bench_kernel(0, 40)          # several launches, buffer keeps the last one

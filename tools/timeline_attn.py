@@ -15,7 +15,6 @@ tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], ctx)      # fill th
 api.synchronize()
 print("pos", tr.pos())
 dbg = api.DevBuf(nbytes=32 * 16 * 8 * 8 + 4096)
-L.q4_set_debug_buffer.argtypes = [C.c_void_p]; L.q4_set_debug_buffer(dbg.ptr)
 L.q4_set_use_graphs(0)
 print("attention graph-mode us/launch:", tr.bench_kernel_graph(6, 32, 20))
 tr.bench_kernel(6, 40)
