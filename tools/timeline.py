@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama_cu_awq_amd import api, synth
+api.use_profiling_build()   # the measurement knobs live in libllama2_q4_prof.so only
 path = "/tmp/llama2_q4_synth_7b_seed20240229.bin"
 if not os.path.exists(path):
     synth.write_model(path, "7b")
