@@ -38,9 +38,12 @@ struct AttArgs {
 };
 
 // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
-template <int LPR, int U, int NW, bool FUSED>
+// FUSED: 0 stand-alone; 1 attention role of the QKV -> attention -> o-proj launch (waits for the head's q / k / v granules, publishes
+// its output as granules); 2 attention role of the attention -> o-proj launch (inputs from the previous launch, publishes granules)
+template <int LPR, int U, int NW, int FUSED>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
+    constexpr bool WAIT_IN = FUSED == 1, PUB = FUSED != 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
     if (!FUSED && a.dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,7 +67,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
     // context <= `group` positions (rows past the position are not requested at all). FUSED: the row of the current
     // position does not exist yet -- it follows after the hand-off
-    const int ready = FUSED ? size - 1 : size;
+    const int ready = WAIT_IN ? size - 1 : size;
     u32x4 kv0[U], vv0[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -77,7 +80,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
         }
     }
     u32x4 qv;
-    if (FUSED) {
+    if (WAIT_IN) {
         // q and the k / v rows of the current position arrive as granules from the head's QKV blocks of this launch:
         // head_size/2 = 64 granules per vector, one per lane of wave 0, polled until all three vectors carry the tag
         // (these 12 lines are polled by this block only)
@@ -125,7 +128,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
                 kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
-                if (FUSED && tc == size - 1) kv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 64)[sub];   // this launch's row
+                if (WAIT_IN && tc == size - 1) kv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 64)[sub];   // this launch's row
             }
         }
 #pragma unroll
@@ -178,7 +181,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
                 vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
-                if (FUSED && tc == size - 1) vv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 128)[sub];
+                if (WAIT_IN && tc == size - 1) vv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 128)[sub];
             }
         }
 #pragma unroll
@@ -218,7 +221,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     }
     if (!FUSED && a.dbg) ts[5] = __builtin_readcyclecounter();
     __syncthreads();                                                              // barrier 3: output partials
-    if (FUSED) {
+    if (PUB) {
         // one granule (two outputs) per thread of wave 0, ONE store instruction per head, validated by its tag on the
         // o-proj side; the plain copy keeps RunState::xb what the launch sequence leaves there
         if ((int)tid < head_size / 2) {
@@ -259,7 +262,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
 
 template <int LPR, int U = 4, int NW = ATT_NW>
 __global__ void __launch_bounds__(NW * 64) attention_kernel(const AttArgs a) {
-    attention_body<LPR, U, NW, false>(a, blockIdx.x, Handoff{});
+    attention_body<LPR, U, NW, 0>(a, blockIdx.x, Handoff{});
 }
 
 }  // namespace q4

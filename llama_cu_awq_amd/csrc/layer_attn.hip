@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_block_kernel(const At
     } else if (b < a.nq + a.nheads) {
         ho.sub = g_qkv;
         ho.pub = g_att;
-        attention_body<16, U, LA_WAVES, true>(a.att, (int)(b - a.nq), ho);
+        attention_body<16, U, LA_WAVES, 1>(a.att, (int)(b - a.nq), ho);
     } else {
         const unsigned j = b - a.nq - a.nheads;
         ho.sub = g_att;
@@ -65,7 +65,76 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_block_kernel(const At
 #endif
 }
 
+// attention -> o-proj as one launch (fusion level 3): the QKV GEMV keeps its own launch in its tuned 4-wave shape; here the
+// attention heads run as they do stand-alone (8 waves), and the o-proj blocks pull their weights while the heads work
+struct AttOprojArgs {
+    GemvArgs oproj;
+    AttArgs att;
+    unsigned* sync;
+    unsigned nheads, no;
+    unsigned long long* dbg;
+};
+
+template <int SLOTS, bool HALF, int U>
+__global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const AttOprojArgs a) {
+    const unsigned b = blockIdx.x;
+    Handoff ho = {};
+    ho.error = a.sync;
+    unsigned* epoch = a.sync + 64;                      // this launch's own epoch word
+    ho.tag = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    u32x2v* g_att = reinterpret_cast<u32x2v*>(a.sync + 1024) + 3 * (size_t)(a.oproj.N / 2);
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = b < a.nheads ? 1 : 2; }
+    ho.stamp = a.dbg ? a.dbg + b * 4 + 1 : nullptr;
+#endif
+    if (b < a.nheads) {
+        ho.pub = g_att;
+        attention_body<16, U, LA_WAVES, 2>(a.att, (int)b, ho);
+    } else {
+        const unsigned j = b - a.nheads;
+        ho.sub = g_att;
+        ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);
+        gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
+        if (b == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_fetch_add(epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) a.dbg[b * 4 + 2] = wall_clock64();
+#endif
+}
+
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
+
+int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
+                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync) {
+    const int head_size = dim / n_heads;
+    const QGeom g = make_geom(dim, dim);
+    AttOprojArgs a = {};
+    a.att = {xb, q, key_cache, value_cache, head_size, 1, dim, pPos, (float)(1.0 / sqrt((double)head_size)), seq_len_bin, nullptr};
+    GemvArgs& oa = a.oproj;
+    oa.K = dim; oa.N = dim; oa.pw4 = g.pw4; oa.pzh = g.pzh; oa.sh = g.sh; oa.nslots = g.nslots;
+    fill_mat(oa.m[0], wo);
+    oa.out[0] = x; oa.x = xb; oa.accum = 1; oa.loff = -1;
+    a.sync = sync;
+    a.nheads = n_heads;
+    a.no = dim / (LA_WAVES * 4);
+#ifdef Q4_PROFILING
+    a.dbg = g_dbg;
+#endif
+    const int TS = g.nslots;
+    const size_t smem_gemv = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
+    const size_t smem_att = (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem = smem_gemv > smem_att ? smem_gemv : smem_att;
+    const dim3 grid(a.nheads + a.no), block(LA_WAVES * 64);
+    if (g.nslots == 2) {
+        if (seq_len_bin <= 128) Q4_LAUNCH((attention_oproj_kernel<2, false, 4>), grid, block, smem, a);
+        else Q4_LAUNCH((attention_oproj_kernel<2, false, 8>), grid, block, smem, a);
+    } else {
+        if (seq_len_bin <= 128) Q4_LAUNCH((attention_oproj_kernel<3, true, 4>), grid, block, smem, a);
+        else Q4_LAUNCH((attention_oproj_kernel<3, true, 8>), grid, block, smem, a);
+    }
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
 
 // words of hand-off state a model needs for this launch: the error + epoch page, then 4 granule vectors of dim/2 x 8 bytes
 size_t attention_block_sync_words(int dim, int n_heads) {

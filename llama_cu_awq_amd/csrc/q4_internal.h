@@ -76,6 +76,8 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
                            const QWeight* wq, const QWeight* wk, const QWeight* wv, const QWeight* wo, int dim, int n_heads,
                            long long loff, const int* pPos, float rope_theta, const float2* rope_table, int seq_len_bin,
                            unsigned* sync);
+int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
+                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync);
 extern int g_att_split_min;
 extern int g_la_early;
 extern int g_multi_steps;

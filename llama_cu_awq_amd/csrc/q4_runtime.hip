@@ -124,7 +124,7 @@ int q4_memset(void* dst, int value, size_t bytes) {
     return Q4_OK;
 }
 
-void q4_set_fusion(int level) { g_fusion = level < 0 ? 0 : level > 2 ? 2 : level; q4_reset_graphs(); }
+void q4_set_fusion(int level) { g_fusion = level < 0 ? 0 : level > 3 ? 3 : level; q4_reset_graphs(); }
 int q4_get_fusion(void) { return g_fusion; }
 void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
 void q4_set_quiet(int quiet) { g_quiet = quiet; }
@@ -436,11 +436,17 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
+        if (g_fusion == 3 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
+            // :320-323 in ONE launch: the attention heads hand their output to the o-proj blocks inside the launch
+            Q4_UNLESS(6, launch_attention_oproj(x, s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, dim, p->n_heads,
+                                                pPos, seq_len_bin, sync));
+        } else {
         Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
                                       seq_len_bin, pPos, (float*)s->att,
                                       (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half),
                                       sync && p->n_heads <= 512 ? sync + 128 : nullptr));              // :320
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
+        }
         }
         if (g_fusion) {
             Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329

@@ -33,7 +33,7 @@ def _logit_close(gpu, ref, bound=5e-3):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120"])
-@pytest.mark.parametrize("fusion,graphs", [(2, 1), (1, 1), (0, 1), (2, 0), (1, 0), (0, 0)])
+@pytest.mark.parametrize("fusion,graphs", [(3, 1), (2, 1), (1, 1), (0, 1), (3, 0), (2, 0), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()
     L.q4_set_fusion(fusion)
@@ -81,7 +81,7 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
     L = q4.lib()
     outs = {}
     try:
-        for fusion in (2, 1, 0):
+        for fusion in (3, 2, 1, 0):
             L.q4_set_fusion(fusion)
             t = q4.Transformer(models[name])
             t.reset([1, 5, 9])
@@ -100,18 +100,19 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
     # levels 1 and 2 run the same device code; in the first bin also in the same shapes: identical bits up to position 127.
     # From bin 256 on the fused launch's attention role works with 8 waves x 8 rows in flight, the stand-alone kernel with
     # 16 x 4 (faster on its own): another fp32 summation grouping, so from there on the comparison is the model's bound
-    ring_equal = True
-    for i, (a, b, pos) in enumerate(zip(outs[1][0], outs[2][0], checkpoints)):
-        if pos < 128:
-            assert np.array_equal(a, b), "logits differ at position %d (fusion 1 vs 2)" % pos
-        else:
-            ring_equal = ring_equal and outs[1][1][:pos + 1] == outs[2][1][:pos + 1]
-            if not ring_equal:
-                assert pos > 200, "token rings diverged early (%d)" % pos
-                break
-            af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
-            assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), pos
-    assert outs[1][1][:128] == outs[2][1][:128]
+    for lvl in (2, 3):
+        ring_equal = True
+        for i, (a, b, pos) in enumerate(zip(outs[1][0], outs[lvl][0], checkpoints)):
+            if pos < 128:
+                assert np.array_equal(a, b), "logits differ at position %d (fusion 1 vs %d)" % (pos, lvl)
+            else:
+                ring_equal = ring_equal and outs[1][1][:pos + 1] == outs[lvl][1][:pos + 1]
+                if not ring_equal:
+                    assert pos > 200, "token rings diverged early (%d, fusion %d)" % (pos, lvl)
+                    break
+                af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
+                assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), (pos, lvl)
+        assert outs[1][1][:128] == outs[lvl][1][:128]
     # level 0 (the reference's 1:1 sequence): identical too, except where K = dim ends in a shared half slot (K = 5120):
     # there a column's half-slot terms sit in the lower or the upper 32 lanes depending on its place in the wave, and the
     # RoPE-paired column order of the fused QKV differs from the plain one -- same terms, another fp32 rounding sequence

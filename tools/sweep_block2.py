@@ -26,7 +26,7 @@ def secs(n):
     return min(tr.generate_ids(prompt, n)[3] for _ in range(3))
 
 
-for fusion, early, att8 in ((1, 0, 0), (1, 0, 1), (2, 8 | (8 << 8), 1), (2, 0, 1)):
+for fusion, early, att8 in ((1, 0, 0), (3, 0, 0), (2, 8 | (8 << 8), 0), (1, 0, 0), (3, 0, 0)):
     L.q4_set_fusion(fusion)
     L.q4_set_gemv_early(4, early)
     L.q4_set_gemv_early(6, att8)
