@@ -218,11 +218,13 @@ int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p
 int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p, RunState* s, const TransformerWeights* w,
                              int copyLogits, Sampler* pSampler);
 
-/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1 (default): fused kernels (rmsnorm folded into the
- * consumer GEMV, RoPE + KV write in the QKV epilogue: 5 launches/layer); 2: additionally QKV -> attention -> o-proj
- * (llama2_q4.cu:300-323) as ONE launch with in-launch hand-offs where the geometry has that form (multi-head, head 128,
- * bins <= 512), 3 launches/layer -- bit-identical to level 1, measured 0.3-1.5 % slower on MI355X, kept as an
- * option. Resets captured graphs. */
+/* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1: fused kernels (rmsnorm folded into the consumer GEMV,
+ * RoPE + KV write in the QKV epilogue: 5 launches/layer); 3 (default): additionally attention -> o-proj (llama2_q4.cu:320-323)
+ * as ONE launch where the geometry has that form (multi-head, head 128): the o-proj blocks pull their weights while the heads
+ * work and take the heads' output inside the launch (bounded waits, q4_handoff_status), 4 launches/layer; 2: QKV -> attention
+ * -> o-proj (:300-323) as one launch, 3 launches/layer -- measured slower than level 1 on MI355X, kept as an option.
+ * Levels 1-3 run the same arithmetic (identical bits in the first bin, the model's tolerance above it: the attention role
+ * groups its fp32 sums by 8 waves). Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */

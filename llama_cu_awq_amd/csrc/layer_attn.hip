@@ -66,17 +66,21 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_block_kernel(const At
 }
 
 // attention -> o-proj as one launch (fusion level 3): the QKV GEMV keeps its own launch in its tuned 4-wave shape; here the
-// attention heads run as they do stand-alone (8 waves), and the o-proj blocks pull their weights while the heads work
+// attention runs in 8-wave blocks -- ATT 0: one block per head, 4 rows in flight per lane (first bin); 1: 8 rows (bin 256);
+// 2 / 3: one block per (head, 128 / 256 positions), merged by each head's last block (bins >= 512) -- and the o-proj blocks
+// (8 waves as well) pull their weights while the heads work.
 struct AttOprojArgs {
     GemvArgs oproj;
     AttArgs att;
+    SplitArgs split;
     unsigned* sync;
-    unsigned nheads, no;
+    unsigned nheads, natt, no;       // heads, attention blocks (heads, or heads x chunks), o-proj blocks
     unsigned long long* dbg;
 };
 
-template <int SLOTS, bool HALF, int U>
+template <int SLOTS, bool HALF, int ATT>
 __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const AttOprojArgs a) {
+    constexpr int NW = LA_WAVES;       // 8-wave blocks for both roles: 16-wave o-proj blocks (64 of them) lost 13-20 us per token
     const unsigned b = blockIdx.x;
     Handoff ho = {};
     ho.error = a.sync;
@@ -84,14 +88,15 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
     ho.tag = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     u32x2v* g_att = reinterpret_cast<u32x2v*>(a.sync + 1024) + 3 * (size_t)(a.oproj.N / 2);
 #ifdef Q4_PROFILING
-    if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = b < a.nheads ? 1 : 2; }
+    if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = b < a.natt ? 1 : 2; }
     ho.stamp = a.dbg ? a.dbg + b * 4 + 1 : nullptr;
 #endif
-    if (b < a.nheads) {
+    if (b < a.natt) {
         ho.pub = g_att;
-        attention_body<16, U, LA_WAVES, 2>(a.att, (int)b, ho);
+        if constexpr (ATT <= 1) attention_body<16, ATT == 0 ? 4 : 8, NW, 2>(a.att, (int)b, ho);
+        else attention_split_body<16, ATT == 2 ? 4 : 8, true, NW>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
     } else {
-        const unsigned j = b - a.nheads;
+        const unsigned j = b - a.natt;
         ho.sub = g_att;
         ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);
         gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
@@ -104,34 +109,55 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
 
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
 
+// geometry that has this form: multi-head, head 128, K = dim in 2 slots or 3 with a shared half slot; any bin the attention
+// kernels cover (the split form needs the scratch)
+bool attention_oproj_supported(int dim, int kv_dim, int head_size) {
+    const QGeom g = make_geom(dim, dim);
+    const bool slots_ok = g.nslots == 2 || (g.nslots == 3 && g.pw4 - 2 * 64 <= 32);
+    return dim == kv_dim && head_size == 128 && slots_ok && (dim % 64) == 0;
+}
+
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync) {
+                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
+                           float* scratch, size_t scratch_bytes, int split_min, int split_chunk) {
     const int head_size = dim / n_heads;
     const QGeom g = make_geom(dim, dim);
+    const float alpha = (float)(1.0 / sqrt((double)head_size));
+    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 512 ? 128 : 256);
+    const int nsp = divUp(seq_len_bin, chunk);
+    const bool split = seq_len_bin >= split_min && scratch != nullptr && n_heads <= 512 &&
+                       (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
+    const int att = split ? (chunk == 128 ? 2 : 3) : seq_len_bin <= 128 ? 0 : 1;
+    const int nw = LA_WAVES;
     AttOprojArgs a = {};
-    a.att = {xb, q, key_cache, value_cache, head_size, 1, dim, pPos, (float)(1.0 / sqrt((double)head_size)), seq_len_bin, nullptr};
+    a.att = {xb, q, key_cache, value_cache, head_size, 1, dim, pPos, alpha, seq_len_bin, nullptr};
+    a.split = {scratch, q, key_cache, value_cache, head_size, 1, dim, pPos, alpha, xb, sync + 128};
     GemvArgs& oa = a.oproj;
     oa.K = dim; oa.N = dim; oa.pw4 = g.pw4; oa.pzh = g.pzh; oa.sh = g.sh; oa.nslots = g.nslots;
     fill_mat(oa.m[0], wo);
     oa.out[0] = x; oa.x = xb; oa.accum = 1; oa.loff = -1;
     a.sync = sync;
     a.nheads = n_heads;
-    a.no = dim / (LA_WAVES * 4);
+    a.natt = split ? n_heads * nsp : n_heads;
+    a.no = dim / (nw * 4);
 #ifdef Q4_PROFILING
     a.dbg = g_dbg;
 #endif
     const int TS = g.nslots;
     const size_t smem_gemv = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
-    const size_t smem_att = (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem_att = split ? (size_t)(32 + nw * head_size) * 4 : (size_t)(32 + nw * head_size + seq_len_bin) * 4;
     const size_t smem = smem_gemv > smem_att ? smem_gemv : smem_att;
-    const dim3 grid(a.nheads + a.no), block(LA_WAVES * 64);
-    if (g.nslots == 2) {
-        if (seq_len_bin <= 128) Q4_LAUNCH((attention_oproj_kernel<2, false, 4>), grid, block, smem, a);
-        else Q4_LAUNCH((attention_oproj_kernel<2, false, 8>), grid, block, smem, a);
-    } else {
-        if (seq_len_bin <= 128) Q4_LAUNCH((attention_oproj_kernel<3, true, 4>), grid, block, smem, a);
-        else Q4_LAUNCH((attention_oproj_kernel<3, true, 8>), grid, block, smem, a);
+    if (smem > 64 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;
+    const dim3 grid(a.natt + a.no), block(nw * 64);
+#define Q4_AO(S, H)                                                                            \
+    switch (att) {                                                                             \
+        case 0: Q4_LAUNCH((attention_oproj_kernel<S, H, 0>), grid, block, smem, a); break;     \
+        case 1: Q4_LAUNCH((attention_oproj_kernel<S, H, 1>), grid, block, smem, a); break;     \
+        case 2: Q4_LAUNCH((attention_oproj_kernel<S, H, 2>), grid, block, smem, a); break;     \
+        default: Q4_LAUNCH((attention_oproj_kernel<S, H, 3>), grid, block, smem, a); break;    \
     }
+    if (g.nslots == 2) Q4_AO(2, false) else Q4_AO(3, true)
+#undef Q4_AO
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }

@@ -118,203 +118,7 @@ __global__ void rope_kernel(q4_half* sq, q4_half* sk_base, int num_kv_heads, int
 
 // ------------------------------------------------------------------------------------------------
 // MultiHeadAttention: attention_body / attention_kernel live in attention.h (shared with the fused launch, layer_attn.hip)
-// Long contexts: the same block, but one per (head, 256-position chunk) so that all CUs pull on the KV cache (at
-// pos 2047 a layer's K+V is 32 MB; 32 single-head blocks would stream it at a few CUs' worth of bandwidth). Each
-// block leaves a flash-decode partial -- un-normalised acc[head_size], running max m, sum l of exp(s - m), fp32 -- in the
-// `att` scratch (RunState::att, the buffer the reference keeps its scores in); the partials are merged as
-//     out = sum_s exp(m_s - M) acc_s / sum_s exp(m_s - M) l_s      (fixed order over the chunks).
-// Scores are still rounded through fp16 (:167); the probabilities stay fp32 here (the reference rounds them to fp16,
-// :400 -- a <= 2^-11 relative difference).
-// Two ways to merge: the LAST block of a head to finish does it (arrive != nullptr: partial written through (sc1), drained,
-// one returning arrival on the head's counter; nobody waits for anybody, the last arriver re-arms the counter), or
-// attention_combine_kernel in a second launch (the public q4_multi_head_attention, whose caller owns the scratch).
-constexpr int ATT_REC_PAD = 4;   // a partial record is head_size + 4 floats: acc[head_size], m, l, 2 x pad (16-byte rows)
-
-// merge the nsp partial records of one head for output n. The loads of a batch of 8 chunks go out together (a loop
-// of dependent loads costs one memory latency per chunk: the stand-alone combine kernel spent 4.8 us on 8 chunks that way);
-// the arithmetic is strictly in chunk order, whatever the batching.
-template <bool SC1>
-__device__ __forceinline__ void combine_partials(q4_half* out_head, const float* base, int head_size, int nsp, int n) {
-    const int rec = head_size + ATT_REC_PAD;
-    auto ld = [&](const float* p) -> float {
-        return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-    };
-    constexpr int B = 8;
-    float M = -INFINITY, denom = 0.f, num = 0.f;
-    if (nsp <= B) {                      // one round trip: m, l and acc[n] of every chunk
-        float mv[B], lv[B], av[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-            const float* ps = base + (size_t)(k < nsp ? k : 0) * rec;
-            mv[k] = ld(ps + head_size); lv[k] = ld(ps + head_size + 1); av[k] = ld(ps + n);
-        }
-#pragma unroll
-        for (int k = 0; k < B; k++) if (k < nsp) M = fmaxf(M, mv[k]);
-#pragma unroll
-        for (int k = 0; k < B; k++) if (k < nsp) denom += lv[k] * expf(mv[k] - M);
-#pragma unroll
-        for (int k = 0; k < B; k++)
-            if (k < nsp) { const float w = expf(mv[k] - M); num += w > 0.f ? av[k] * w : 0.f; }   // neutral chunks hold no acc
-    } else {
-        for (int s0 = 0; s0 < nsp; s0 += B) {
-            float mv[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) mv[k] = ld(base + (size_t)(s0 + k < nsp ? s0 + k : 0) * rec + head_size);
-#pragma unroll
-            for (int k = 0; k < B; k++) if (s0 + k < nsp) M = fmaxf(M, mv[k]);
-        }
-        for (int s0 = 0; s0 < nsp; s0 += B) {
-            float mv[B], lv[B], av[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const float* ps = base + (size_t)(s0 + k < nsp ? s0 + k : 0) * rec;
-                mv[k] = ld(ps + head_size); lv[k] = ld(ps + head_size + 1); av[k] = ld(ps + n);
-            }
-#pragma unroll
-            for (int k = 0; k < B; k++)
-                if (s0 + k < nsp) {
-                    const float w = expf(mv[k] - M);
-                    denom += lv[k] * w;
-                    num += w > 0.f ? av[k] * w : 0.f;
-                }
-        }
-    }
-    out_head[n] = f2h(num / denom);
-}
-
-template <int LPR, int U>
-__global__ void __launch_bounds__(ATT_NW * 64) attention_split_kernel(float* partials, const q4_half* q, const q4_half* key_cache,
-                                                                      const q4_half* value_cache, int head_size, int kv_mul,
-                                                                      int kv_dim, const int* pPos, float alpha, q4_half* output,
-                                                                      unsigned* arrive) {
-    constexpr int R = 64 / LPR, NW = ATT_NW;
-    constexpr int stride = NW * R;
-    constexpr int ATT_CHUNK = stride * U;                    // positions per block = one register-resident group
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red_max = reinterpret_cast<float*>(smem);
-    float* red_sum = red_max + 16;
-    float* outp = red_sum + 16;                              // [NW][head_size]
-    __shared__ int is_last;
-    const int h = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
-    const unsigned tid = threadIdx.x, lane = tid & 63u;
-    const int wave = tid >> 6;
-    const int row = lane / LPR, sub = lane % LPR;
-    const int size = *pPos + 1;
-    const int t_base = sp * ATT_CHUNK;
-    const int rec = head_size + ATT_REC_PAD;
-    float* my = partials + ((size_t)h * nsp + sp) * rec;
-    const bool live = t_base < size;                         // chunk entirely in the future: neutral partial (m = -inf, l = 0)
-    if (live) {
-        const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-        const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
-        // non-temporal: at these contexts the KV cache (>= 0.5 GB per token) does not stay in the 256 MB Infinity Cache;
-        // the one-block kernel for short contexts keeps the default policy (its 128 MB per token does: 4.1 vs 4.6 us)
-        u32x4 kv[U], vv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = t_base + wave * R + row + u * stride;
-            const int tc = t < size ? t : size - 1;
-            kv[u] = ld_nt(reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim));
-            vv[u] = ld_nt(reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim));
-        }
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
-        float sc[U];
-        float wmax = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = t_base + wave * R + row + u * stride;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[u][e]), as_h2(qv[e]), s, false);
-            s = row_sum<LPR>(s);
-            s = round_h(s * alpha);
-            sc[u] = t < size ? s : -INFINITY;
-            wmax = fmaxf(wmax, sc[u]);
-        }
-        wmax = wave_max(wmax);
-        if (lane == 0) red_max[wave] = wmax;
-        __syncthreads();
-        const float m = row16_max(red_max[lane & 15]);
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] = 0.f;
-        float lsum = 0.f;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float p = expf(sc[u] - m);                     // 0 for masked positions (sc = -inf)
-            if (sub == 0) lsum += p;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const h2 v2 = as_h2(vv[u][e]);
-                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);
-                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
-            }
-        }
-        lsum = wave_sum(lsum);
-        if (lane == 0) red_sum[wave] = lsum;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float v = acc[e];
-            if (LPR <= 32) v += __shfl_xor(v, 32);
-            if (LPR <= 16) v += __shfl_xor(v, 16);
-            if (LPR <= 8) v += __shfl_xor(v, 8);
-            if (LPR <= 4) v += __shfl_xor(v, 4);
-            acc[e] = v;
-        }
-        if (lane < LPR) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
-        }
-        __syncthreads();
-        const float l = row16_sum(red_sum[lane & 15]);
-        // the record leaves as 16-byte stores: thread n4 sums the NW wave partials of outputs 4*n4 .. 4*n4+3
-        if ((int)tid <= head_size / 4) {
-            f32x4 r4;
-            if ((int)tid < head_size / 4) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int n = tid * 4 + k;
-                    float part[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
-                    float s = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) s += part[w];
-                    r4[k] = s;
-                }
-            } else {
-                r4 = (f32x4){m, l, 0.f, 0.f};
-            }
-            float* dst = my + tid * 4;
-            if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
-            else *reinterpret_cast<f32x4*>(dst) = r4;
-        }
-    } else if (tid == 0) {
-        const f32x4 r4 = {-INFINITY, 0.f, 0.f, 0.f};
-        float* dst = my + head_size;
-        if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
-        else *reinterpret_cast<f32x4*>(dst) = r4;
-    }
-    if (arrive == nullptr) return;
-    // ---- last-arriver merge: record drained to memory, then ONE returning arrival per block ------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = old == (unsigned)nsp - 1u;
-        if (is_last) __hip_atomic_store(arrive + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-    }
-    __syncthreads();
-    if (!is_last) return;
-    for (int n = tid; n < head_size; n += NW * 64)
-        combine_partials<true>(output + (size_t)h * head_size, partials + (size_t)h * nsp * rec, head_size, nsp, n);
-}
-
-__global__ void attention_combine_kernel(q4_half* output, const float* partials, int head_size, int nsp) {
-    const int h = blockIdx.x;
-    for (int n = threadIdx.x; n < head_size; n += blockDim.x)
-        combine_partials<false>(output + (size_t)h * head_size, partials + (size_t)h * nsp * (head_size + ATT_REC_PAD), head_size, nsp, n);
-}
+// Long contexts: attention_split_body / attention_split_kernel / attention_combine_kernel live in attention.h
 
 // ------------------------------------------------------------------------------------------------
 // copy_embedding_kernel (gpu_kernels.h:61-69); 16-byte copies. tokens may live in mapped host memory.
@@ -561,8 +365,8 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     if (split) {
         const size_t smem = (size_t)(32 + ATT_NW * head_size) * 4;
         const dim3 grid(num_heads, nsp);
-#define Q4_SPLIT(L, UU) Q4_LAUNCH((attention_split_kernel<L, UU>), grid, block, smem, scratch, q, key_cache, value_cache, head_size, \
-                                  kv_mul, kv_dim, pPos, alpha, output, arrive)
+        const SplitArgs sa = {scratch, q, key_cache, value_cache, head_size, kv_mul, kv_dim, pPos, alpha, output, arrive};
+#define Q4_SPLIT(L, UU) Q4_LAUNCH((attention_split_kernel<L, UU>), grid, block, smem, sa)
         if (head_size == 64) Q4_SPLIT(8, 2);                 // 16 waves x 8 rows x 2 = 256 positions per block
         else if (head_size == 256) Q4_SPLIT(32, 8);          // 16 x 2 x 8
         else if (chunk == 128) Q4_SPLIT(16, 2);

@@ -14,7 +14,7 @@
 namespace q4 {
 
 hipStream_t g_stream = nullptr;
-int g_fusion = 1;
+int g_fusion = 3;
 int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
@@ -436,10 +436,12 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
-        if (g_fusion == 3 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
+        const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
+        if (g_fusion == 3 && sync && attention_oproj_supported(dim, kv_dim, head_size) &&
+            (size_t)(32 + 16 * head_size + (seq_len_bin >= g_att_split_min ? 0 : seq_len_bin)) * 4 <= 64 * 1024) {
             // :320-323 in ONE launch: the attention heads hand their output to the o-proj blocks inside the launch
             Q4_UNLESS(6, launch_attention_oproj(x, s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, dim, p->n_heads,
-                                                pPos, seq_len_bin, sync));
+                                                pPos, seq_len_bin, sync, (float*)s->att, att_bytes, g_att_split_min, g_att_chunk));
         } else {
         Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
                                       seq_len_bin, pPos, (float*)s->att,

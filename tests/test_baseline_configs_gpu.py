@@ -142,7 +142,7 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     split-context attention from bin 1024 on), then compare ONE more step with the restatement started from the GPU's
     own KV cache -- no 2000-step CPU run, and every cached position takes part in the compared step's attention."""
     L = q4.lib()
-    assert L.q4_get_fusion() == 1
+    assert L.q4_get_fusion() == 3
     t = q4.Transformer(m7b)
     m = orc.Model(m7b)
     toks, tps, timed, _ = t.generate_ids(PROMPT, target)          # positions 0 .. target-1 (graphs of 128 .. 2048)

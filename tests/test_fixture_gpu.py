@@ -11,7 +11,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fusion", [1, 0])
+@pytest.mark.parametrize("fusion", [3, 1, 0])
 def test_micro_model_against_committed_goldens(q4, fusion):
     L = q4.lib()
     L.q4_set_fusion(fusion)
@@ -44,4 +44,4 @@ def test_micro_model_against_committed_goldens(q4, fusion):
                 assert np.abs(gv.astype(np.float32) - exp["v"][layer, pos].astype(np.float32)).max() < 1e-4
         t.close()
     finally:
-        L.q4_set_fusion(1)
+        L.q4_set_fusion(3)

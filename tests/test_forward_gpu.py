@@ -67,7 +67,7 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
         t.close()
         m.close()
     finally:
-        L.q4_set_fusion(1)
+        L.q4_set_fusion(3)
         L.q4_set_use_graphs(1)
 
 
@@ -96,7 +96,7 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
             outs[fusion] = (got, ring)
             t.close()
     finally:
-        L.q4_set_fusion(1)
+        L.q4_set_fusion(3)
     # levels 1 and 2 run the same device code; in the first bin also in the same shapes: identical bits up to position 127.
     # From bin 256 on the fused launch's attention role works with 8 waves x 8 rows in flight, the stand-alone kernel with
     # 16 x 4 (faster on its own): another fp32 summation grouping, so from there on the comparison is the model's bound
@@ -179,7 +179,7 @@ def test_fused_equals_unfused_bits(q4, models, name):
         q4.synchronize()
         outs.append(t.logits().copy())
         t.close()
-    L.q4_set_fusion(1)
+    L.q4_set_fusion(3)
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
 
 
