@@ -238,7 +238,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
                 xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
                 if (g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag) break;
                 if (tries >= POLL_LIMIT / 4) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
         }
         return ok;
@@ -359,7 +359,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
         if (tid == 0) {            // one lane polls ONE granule (spread over lines: few pollers per line) ...
             unsigned i = 0;
-            while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(8);
+            while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
             if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
