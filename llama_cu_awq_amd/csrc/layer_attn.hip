@@ -114,11 +114,11 @@ static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->z
 bool attention_oproj_supported(int dim, int kv_dim, int head_size) {
     const QGeom g = make_geom(dim, dim);
     const bool slots_ok = g.nslots == 2 || (g.nslots == 3 && g.pw4 - 2 * 64 <= 32);
-    return dim == kv_dim && head_size == 128 && slots_ok && (dim % 64) == 0;
+    return kv_dim > 0 && dim % kv_dim == 0 && head_size == 128 && slots_ok && (dim % 64) == 0;      // multi-head or grouped-query
 }
 
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
+                           const QWeight* wo, int dim, int kv_dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
                            float* scratch, size_t scratch_bytes, int split_min, int split_chunk) {
     const int head_size = dim / n_heads;
     const QGeom g = make_geom(dim, dim);
@@ -130,8 +130,9 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     const int att = split ? (chunk == 128 ? 2 : 3) : seq_len_bin <= 128 ? 0 : 1;
     const int nw = LA_WAVES;
     AttOprojArgs a = {};
-    a.att = {xb, q, key_cache, value_cache, head_size, 1, dim, pPos, alpha, seq_len_bin, nullptr};
-    a.split = {scratch, q, key_cache, value_cache, head_size, 1, dim, pPos, alpha, xb, sync + 128};
+    const int kv_mul = dim / kv_dim;
+    a.att = {xb, q, key_cache, value_cache, head_size, kv_mul, kv_dim, pPos, alpha, seq_len_bin, nullptr};
+    a.split = {scratch, q, key_cache, value_cache, head_size, kv_mul, kv_dim, pPos, alpha, xb, sync + 128};
     GemvArgs& oa = a.oproj;
     oa.K = dim; oa.N = dim; oa.pw4 = g.pw4; oa.pzh = g.pzh; oa.sh = g.sh; oa.nslots = g.nslots;
     fill_mat(oa.m[0], wo);

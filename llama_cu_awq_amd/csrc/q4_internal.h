@@ -78,7 +78,7 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
                            unsigned* sync);
 bool attention_oproj_supported(int dim, int kv_dim, int head_size);
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
-                           const QWeight* wo, int dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
+                           const QWeight* wo, int dim, int kv_dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
                            float* scratch, size_t scratch_bytes, int split_min, int split_chunk);
 extern int g_att_chunk;
 extern int g_att_split_min;

@@ -41,6 +41,7 @@ GEOMETRIES = {
     # in three with the shared half slot (13B-like), contexts long enough to cross the 128 / 256 / 512 / 1024 bins
     "head128": (2560, 3584, 2, 20, 20, 512, 1100, 10000.0),
     "head128_k5120": (5120, 1408, 1, 40, 40, 512, 300, 10000.0),
+    "head128_gqa": (2560, 3584, 2, 20, 4, 512, 700, 1000000.0),   # grouped-query (kv_mul 5) with a fused attention + o-proj form
     "head64_long": (512, 1408, 2, 8, 4, 512, 1300, 10000.0),     # head 64, grouped-query, context past the split threshold
     # the sampler at production vocabulary sizes on a one-layer body: 32000 = the register/LDS path with 32 keys per
     # thread, 40000 = the global-memory fallback (> 32 x 1024 entries)

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     out = {}
-    for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head64_long"):
+    for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head64_long", "head128_gqa"):
         p = str(d / (name + ".bin"))
         synth.write_model(p, name, seed=7)
         out[name] = p
@@ -24,7 +24,7 @@ def models(tmp_path_factory):
 
 # measured worst case per model (tools/measure_tolerances.py, profiles/r02_parity_observed.json): one fp16 ulp of an O(1)
 # logit = 9.8e-4 (longk_gqa, logits up to 2.2: 1.7e-3); the bounds are 3x that
-BOUND = {"tiny": 3e-3, "tiny_gqa": 3e-3, "small": 3e-3, "longk_gqa": 5e-3, "head128": 5e-3, "head128_k5120": 5e-3}
+BOUND = {"tiny": 3e-3, "tiny_gqa": 3e-3, "small": 3e-3, "longk_gqa": 5e-3, "head128": 5e-3, "head128_k5120": 5e-3, "head128_gqa": 5e-3}
 
 
 def _logit_close(gpu, ref, bound=5e-3):
@@ -32,7 +32,7 @@ def _logit_close(gpu, ref, bound=5e-3):
     return np.abs(gpu - ref) <= bound * np.maximum(1.0, np.abs(ref))
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head128_gqa"])
 @pytest.mark.parametrize("fusion,graphs", [(3, 1), (2, 1), (1, 1), (0, 1), (3, 0), (2, 0), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()
@@ -72,7 +72,8 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
 
 
 @pytest.mark.parametrize("name,steps,checkpoints", [("head128", 1060, (3, 100, 127, 128, 200, 255, 256, 300, 511, 512, 600, 1023, 1024, 1059)),
-                                                     ("head128_k5120", 290, (3, 127, 128, 200, 255, 256, 289))])
+                                                     ("head128_k5120", 290, (3, 127, 128, 200, 255, 256, 289)),
+                                                     ("head128_gqa", 690, (3, 100, 127, 128, 255, 256, 511, 512, 689))])
 def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name, steps, checkpoints):
     """Fusion level 2 (QKV -> attention -> o-proj as ONE launch, hand-offs inside the launch) against levels 1 and 0
     across the sequence-length bins 128 / 256 / 512 (fused forms) and 1024+ (falls back to the launch sequence): the
@@ -126,7 +127,7 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
         assert outs[0][1] == outs[1][1], "token ring differs at fusion level 0"
 
 
-@pytest.mark.parametrize("name,target", [("head128", 1050), ("head64_long", 1100), ("head64_long", 1290)])
+@pytest.mark.parametrize("name,target", [("head128", 1050), ("head64_long", 1100), ("head64_long", 1290), ("head128_gqa", 600)])
 def test_split_context_merge_by_the_last_block(q4, orc, models, name, target):
     """Bins >= 1024 inside the network: one attention block per (head, 256 positions), merged by each head's LAST block
     (returning arrival on the model's counters, no second launch). Decode `target` positions through the captured graphs,
