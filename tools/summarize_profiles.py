@@ -50,7 +50,7 @@ for d in sorted(glob.glob(os.path.join(src, "trace_*"))):
 
 KERNELS = {0: "gemv_q4_kernel<2", 2: "gemv_q4_kernel<0, 3", 3: "gemv_q4_kernel<1", 4: "gemv_q4_kernel<0, 2", 5: "gemv_f16_kernel", 6: "attention"}
 NAMES = {0: "ffn_rmsnorm_gate_up_silu_q4", 2: "gemv_q4_hidden_to_dim_accum (down)", 3: "qkv_rmsnorm_rope_q4", 4: "gemv_q4_oproj_accum", 5: "classifier_f16",
-         6: "attention (seq_len 2048: split + combine)"}
+         6: "attention, stand-alone one-block kernel (q4_multi_head_attention)"}
 
 
 def qweight_bytes(K, N):
