@@ -793,6 +793,7 @@ float q4_perplexity_ids(Transformer* t, Sampler* sampler, const int* tokens_with
     for (int pos = 0; pos < num_tokens; pos++)
         if (q4_run_transformer_at(pos, 0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
     if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                        // :81
+    if (q4_handoff_status(state)) return -1.0f;                                    // a timed-out in-launch wait: fail loudly
     float* logits_arr = (float*)malloc((size_t)num_tokens * config->vocab_size * sizeof(float));
     if (q4_get_logits_array(t, num_tokens, logits_arr)) { free(logits_arr); return -1.0f; }   // :88-89
     float pplx = compute_perplexity(tokens_with_bos + 1, logits_arr, num_tokens, config->vocab_size);   // :91
