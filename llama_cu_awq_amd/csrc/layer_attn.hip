@@ -111,10 +111,22 @@ static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->z
 
 // geometry that has this form: multi-head, head 128, K = dim in 2 slots or 3 with a shared half slot; any bin the attention
 // kernels cover (the split form needs the scratch)
-bool attention_oproj_supported(int dim, int kv_dim, int head_size) {
+// Which attention form the launch would use for this geometry and bin: 0 / 1 one block per head (4 / 8 rows in flight),
+// 2 / 3 split context (128 / 256 positions per block), or -1 when there is no fused form (the caller then runs the
+// stand-alone launches): multi-head or grouped-query, head 128, K = dim in 2 slots or 3 with a shared half slot, and the
+// one-block form only while its score buffer fits the default 64 KB of LDS.
+int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int seq_len_bin, bool have_scratch, size_t scratch_bytes,
+                         int split_min, int split_chunk) {
     const QGeom g = make_geom(dim, dim);
     const bool slots_ok = g.nslots == 2 || (g.nslots == 3 && g.pw4 - 2 * 64 <= 32);
-    return kv_dim > 0 && dim % kv_dim == 0 && head_size == 128 && slots_ok && (dim % 64) == 0;      // multi-head or grouped-query
+    if (!(kv_dim > 0 && dim % kv_dim == 0 && head_size == 128 && slots_ok && (dim % 64) == 0)) return -1;
+    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 512 ? 128 : 256);
+    const int nsp = divUp(seq_len_bin, chunk);
+    const bool split = seq_len_bin >= split_min && have_scratch && n_heads <= 512 &&
+                       (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
+    if (split) return chunk == 128 ? 2 : 3;
+    if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return -1;
+    return seq_len_bin <= 128 ? 0 : 1;
 }
 
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
@@ -123,11 +135,10 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     const int head_size = dim / n_heads;
     const QGeom g = make_geom(dim, dim);
     const float alpha = (float)(1.0 / sqrt((double)head_size));
-    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 512 ? 128 : 256);
-    const int nsp = divUp(seq_len_bin, chunk);
-    const bool split = seq_len_bin >= split_min && scratch != nullptr && n_heads <= 512 &&
-                       (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
-    const int att = split ? (chunk == 128 ? 2 : 3) : seq_len_bin <= 128 ? 0 : 1;
+    const int att = attention_oproj_form(dim, kv_dim, head_size, n_heads, seq_len_bin, scratch != nullptr, scratch_bytes, split_min, split_chunk);
+    if (att < 0) return Q4_ERR_UNSUPPORTED_SIZE;
+    const bool split = att >= 2;
+    const int nsp = split ? divUp(seq_len_bin, att == 2 ? 128 : 256) : 1;
     const int nw = LA_WAVES;
     AttOprojArgs a = {};
     const int kv_mul = dim / kv_dim;

@@ -76,7 +76,8 @@ int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cac
                            const QWeight* wq, const QWeight* wk, const QWeight* wv, const QWeight* wo, int dim, int n_heads,
                            long long loff, const int* pPos, float rope_theta, const float2* rope_table, int seq_len_bin,
                            unsigned* sync);
-bool attention_oproj_supported(int dim, int kv_dim, int head_size);
+int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int seq_len_bin, bool have_scratch, size_t scratch_bytes,
+                         int split_min, int split_chunk);   // >= 0: the fused attention + o-proj launch covers this case
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                            const QWeight* wo, int dim, int kv_dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
                            float* scratch, size_t scratch_bytes, int split_min, int split_chunk);

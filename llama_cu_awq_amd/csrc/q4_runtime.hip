@@ -437,8 +437,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
         const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
-        if (g_fusion >= 3 && sync && attention_oproj_supported(dim, kv_dim, head_size) &&
-            (size_t)(32 + 16 * head_size + (seq_len_bin >= g_att_split_min ? 0 : seq_len_bin)) * 4 <= 64 * 1024) {
+        if (g_fusion >= 3 && sync &&
+            attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0) {
             // :320-323 in ONE launch: the attention heads hand their output to the o-proj blocks inside the launch
             Q4_UNLESS(6, launch_attention_oproj(x, s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, dim, kv_dim, p->n_heads,
                                                 pPos, seq_len_bin, sync, (float*)s->att, att_bytes, g_att_split_min, g_att_chunk));
