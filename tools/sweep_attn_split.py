@@ -19,7 +19,7 @@ api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 tr = api.Transformer(path)
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
-for chunk, minbin in ((256, 1024), (0, 512), (0, 256), (0, 1024)):
+for chunk, minbin in ((0, 512), (256, 512), (128, 512), (0, 256), (0, 1024), (256, 1024), (0, 512)):
     L.q4_set_attention_split(chunk, minbin)
     tr.generate_ids(prompt, 2048)
     tps = max(tr.generate_ids(prompt, 2048)[1] for _ in range(2))
