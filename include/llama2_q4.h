@@ -213,7 +213,7 @@ int q4_wait_pos(const RunState* s, int pos);
  * token loop may queue Q4_MULTI_STEPS of them as ONE graph replay: q4_steps_that_fit says how many steps (Q4_MULTI_STEPS or
  * 1) may go out at `pos` -- same gen_token for the whole group, one sequence-length bin, within `steps` --, and
  * q4_run_transformer_steps queues them (nsteps = 1 is q4_run_transformer_at). generate() uses the pair. */
-enum { Q4_MULTI_STEPS = 4 };
+enum { Q4_MULTI_STEPS = 8 };
 int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p, const Sampler* sampler);
 int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p, RunState* s, const TransformerWeights* w,
                              int copyLogits, Sampler* pSampler);
