@@ -7,7 +7,8 @@ built by `make -C oracle` into oracle/_ref/). Nothing here is read at test time 
   packer_goldens.json    : sha256 of the reference weight_packer's output (padding nibbles of `zeros` masked,
                            SURVEY P7) on seeded synthetic AWQ dumps, old and new format
   convert_goldens.json   : sha256 of every file the reference convert_awq_to_bin.py writes for a seeded state-dict
-  rng_goldens.json       : xorshift values of sampler.h:31-40 captured from the reference code
+  rng_goldens.json       : output of the reference's own random_u32 / random_f32 (sampler.h:31-40, cut out where the file
+                           lies, compiled with gcc in a scratch directory)
   micro_model.bin/.npz   : a 2-layer checkpoint (synth.py, seed 5) and the CPU restatement's logits / KV / greedy
                            tokens on it -- self-generated (the reference has no runnable GPU path here): they pin the
                            oracle against regressions and give the GPU tests a committed fixture.
@@ -85,10 +86,31 @@ def convert_goldens():
 
 
 def rng_goldens():
-    # sampler.h needs the CUDA runtime headers and does not compile here; values captured from its random_u32 /
-    # random_f32 (pure C, sampler.h:31-40) compiled stand-alone by the survey probe
-    json.dump({"seed": 1, "u32": [1206177355, 2882512552, 3117485455], "f32": [0.28083503, 0.67113721, 0.72584611]},
-              open(os.path.join(HERE, "rng_goldens.json"), "w"), indent=1)
+    """sampler.h as a whole needs the CUDA runtime headers, but random_u32 / random_f32 (sampler.h:31-40) are plain C: the two
+    function definitions are cut out of the reference file WHERE IT LIES into a scratch translation unit (never kept), compiled
+    with gcc and run -- the committed JSON is their output for seed 1."""
+    import re
+    src = open(os.path.join(REF, "sampler.h")).read()
+    m = re.search(r"unsigned int random_u32\(unsigned long long\* state\) \{.*?\n\}\nfloat random_f32\(unsigned long long\* state\) \{.*?\n\}", src, re.S)
+    assert m, "random_u32 / random_f32 not found in the reference's sampler.h"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "rng.c")
+        open(c, "w").write("#include <stdio.h>\n" + m.group(0) + """
+int main(void) {
+    unsigned long long s = 1;
+    printf("{\\"seed\\": 1, \\"u32\\": [");
+    for (int i = 0; i < 3; i++) printf("%s%u", i ? ", " : "", random_u32(&s));
+    s = 1;
+    printf("], \\"f32\\": [");
+    for (int i = 0; i < 3; i++) printf("%s%.8f", i ? ", " : "", random_f32(&s));
+    printf("]}\\n");
+    return 0;
+}
+""")
+        exe = os.path.join(d, "rng")
+        subprocess.check_call(["gcc", "-O1", "-o", exe, c])
+        out = json.loads(subprocess.check_output([exe]).decode())
+    json.dump(out, open(os.path.join(HERE, "rng_goldens.json"), "w"), indent=1)
 
 
 def micro_model():
