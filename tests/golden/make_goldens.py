@@ -9,6 +9,7 @@ built by `make -C oracle` into oracle/_ref/). Nothing here is read at test time 
   convert_goldens.json   : sha256 of every file the reference convert_awq_to_bin.py writes for a seeded state-dict
   rng_goldens.json       : output of the reference's own random_u32 / random_f32 (sampler.h:31-40, cut out where the file
                            lies, compiled with gcc in a scratch directory)
+  perplexity_goldens.json: output of the reference's own softmax / compute_perplexity (perplexity.h:3-51) on seeded logits
   micro_model.bin/.npz   : a 2-layer checkpoint (synth.py, seed 5) and the CPU restatement's logits / KV / greedy
                            tokens on it -- self-generated (the reference has no runnable GPU path here): they pin the
                            oracle against regressions and give the GPU tests a committed fixture.
@@ -113,6 +114,42 @@ int main(void) {
     json.dump(out, open(os.path.join(HERE, "rng_goldens.json"), "w"), indent=1)
 
 
+def perplexity_goldens():
+    """perplexity.h:3-51 (softmax + compute_perplexity, host math in plain C++) cut out of the reference file where it lies into a
+    scratch translation unit, compiled with g++ and run on seeded logits; the committed JSON holds inputs' seed and its output."""
+    import re
+    src = open(os.path.join(REF, "perplexity.h")).read()
+    m = re.search(r"void softmax\(float\* x, int size\) \{.*?\n\}\n.*?float compute_perplexity\(int\* tokens, float\* logits, int num_tokens, int vocab_size\) \{.*?\n\}", src, re.S)
+    assert m, "softmax / compute_perplexity not found in the reference's perplexity.h"
+    n, v, seed = 24, 1000, 20240229
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((n, v)) * 3.0).astype(np.float32)
+    tokens = rng.integers(0, v, size=n).astype(np.int32)
+    with tempfile.TemporaryDirectory() as d:
+        logits.tofile(os.path.join(d, "logits.bin"))
+        tokens.tofile(os.path.join(d, "tokens.bin"))
+        c = os.path.join(d, "ppl.cpp")
+        open(c, "w").write("#include <stdio.h>\n#include <stdlib.h>\n#include <math.h>\n" + m.group(0) + """
+int main(int argc, char** argv) {
+    const int n = atoi(argv[1]), v = atoi(argv[2]);
+    float* logits = (float*)malloc(sizeof(float) * n * v);
+    int* tokens = (int*)malloc(sizeof(int) * n);
+    FILE* f = fopen(argv[3], "rb"); if (fread(logits, sizeof(float), (size_t)n * v, f) != (size_t)n * v) return 1; fclose(f);
+    f = fopen(argv[4], "rb"); if (fread(tokens, sizeof(int), n, f) != (size_t)n) return 1; fclose(f);
+    const float p = compute_perplexity(tokens, logits, n, v);
+    printf("{\\"perplexity\\": %.9g, \\"softmax_row0\\": [", p);
+    for (int i = 0; i < 8; i++) printf("%s%.9g", i ? ", " : "", logits[i]);
+    printf("]}\\n");
+    return 0;
+}
+""")
+        exe = os.path.join(d, "ppl")
+        subprocess.check_call(["g++", "-O1", "-o", exe, c])
+        out = json.loads(subprocess.check_output([exe, str(n), str(v), os.path.join(d, "logits.bin"), os.path.join(d, "tokens.bin")]).decode())
+    out.update({"num_tokens": n, "vocab_size": v, "seed": seed, "logit_scale": 3.0})
+    json.dump(out, open(os.path.join(HERE, "perplexity_goldens.json"), "w"), indent=1)
+
+
 def micro_model():
     import oracle
     path = os.path.join(HERE, "micro_model.bin")
@@ -131,5 +168,6 @@ if __name__ == "__main__":
     packer_goldens()
     convert_goldens()
     rng_goldens()
+    perplexity_goldens()
     micro_model()
     print("goldens written to", HERE)

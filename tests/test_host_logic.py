@@ -58,6 +58,24 @@ def test_rng_goldens(orc):
     assert [L.random_u32(C.byref(s1)) for _ in range(100)] == [orc.lib().orc_random_u32(C.byref(s2)) for _ in range(100)]
 
 
+def test_compute_perplexity_matches_the_reference_golden(orc):
+    """compute_perplexity / softmax of the library and of the oracle against the output of the reference's own perplexity.h:3-51
+    (tests/golden/perplexity_goldens.json, produced by make_goldens.perplexity_goldens from the reference file)."""
+    import ctypes as C
+    from llama_cu_awq_amd import api
+    g = json.load(open(os.path.join(GOLDEN, "perplexity_goldens.json")))
+    n, v = g["num_tokens"], g["vocab_size"]
+    rng = np.random.default_rng(g["seed"])
+    logits = (rng.standard_normal((n, v)) * g["logit_scale"]).astype(np.float32)
+    tokens = rng.integers(0, v, size=n).astype(np.int32)
+    L = api.lib()
+    a = logits.copy()
+    got = L.compute_perplexity(tokens.ctypes.data, a.ctypes.data, n, v)
+    assert got == pytest.approx(g["perplexity"], rel=1e-6)
+    assert np.allclose(a[0, :8], np.array(g["softmax_row0"], dtype=np.float32), rtol=1e-6, atol=0)
+    assert orc.compute_perplexity(tokens, logits) == pytest.approx(g["perplexity"], rel=1e-6)
+
+
 def test_compute_perplexity_matches_oracle_and_numpy(orc):
     rng = np.random.default_rng(0)
     n, v = 17, 300
