@@ -129,6 +129,8 @@ typedef struct {
 /* ---- stream (replaces the file-scope `cudaStream_t stream`, llama2_q4.cu:207,700) ---------- */
 int q4_set_device(int device);
 int q4_stream_create(q4_stream_t* out);          /* cudaStreamCreate, llama2_q4.cu:700 */
+/* a stream restricted to the first n_cus compute units (hipExtStreamCreateWithCUMask): replicas side by side on one GPU */
+int q4_stream_create_masked(q4_stream_t* out, int n_cus);
 int q4_stream_destroy(q4_stream_t s);
 void q4_set_stream(q4_stream_t s);
 q4_stream_t q4_get_stream(void);
@@ -220,11 +222,11 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
 
 /* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1: fused kernels (rmsnorm folded into the consumer GEMV,
  * RoPE + KV write in the QKV epilogue: 5 launches/layer); 3 (default): additionally attention -> o-proj (llama2_q4.cu:320-323)
- * as ONE launch where the geometry has that form (multi-head, head 128): the o-proj blocks pull their weights while the heads
- * work and take the heads' output inside the launch (bounded waits, q4_handoff_status), 4 launches/layer; 2: QKV -> attention
- * -> o-proj (:300-323) as one launch, 3 launches/layer -- measured slower than level 1 on MI355X, kept as an option.
- * Levels 1-3 run the same arithmetic (identical bits in the first bin, the model's tolerance above it: the attention role
- * groups its fp32 sums by 8 waves). Resets captured graphs. */
+ * as ONE launch where the geometry has that form (heads of 64 / 128 / 256, multi-head or grouped-query) and every block of the
+ * launch fits the stream's CUs at once: the o-proj blocks pull their weights while the heads work and take the heads' output
+ * inside the launch (bounded waits, q4_handoff_status), 4 launches/layer. 2 selects 1 (round 2's QKV -> attention -> o-proj
+ * launch was measured slower than level 1 and removed). Levels 1 and 3 run the same arithmetic (identical bits in the first
+ * bin, the model's tolerance above it: the attention role groups its fp32 sums by 8 waves). Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */
@@ -255,9 +257,13 @@ void q4_sampler_delete(Sampler* s);
 /* generate()'s state reset, llama2_q4.cu:461-463: pos = 0, copy prompt tokens into the shared ring */
 int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens);
 int q4_shared_pos(const RunState* s);
-/* Fusion level 2 waits inside a launch with BOUNDED spins; one that ran out sets a sticky device flag and the results
- * from then on are invalid. Synchronises the stream; Q4_OK, or Q4_ERR_HIP with q4_last_error() set. */
+/* Fusion level 3 waits inside a launch with BOUNDED spins; one that ran out sets a device flag and the results from then on
+ * are invalid. Synchronises the stream; Q4_OK, or -- once per incident -- Q4_ERR_HIP with q4_last_error() set, after which
+ * the hand-off state is cleared and the library runs at fusion level 1 (no in-launch waits): redo the sequence
+ * (q4_reset_sequence). q4_generate / q4_generate_ids / q4_perplexity_ids do that themselves, q4_chat reports and stops.
+ * A loop built on q4_run_transformer should call it wherever it synchronises. q4_handoff_timeouts: incidents so far. */
 int q4_handoff_status(const RunState* s);
+int q4_handoff_timeouts(void);
 int q4_shared_token(const RunState* s, int index);
 /* parity dumps: synchronise, then copy fp16 logits / a KV row / the residual to the host */
 int q4_get_logits(const Transformer* t, q4_half* host_out);

@@ -50,7 +50,7 @@ class CliArgs(C.Structure):
 
 # every symbol include/llama2_q4.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "q4_status_string", "q4_last_error", "q4_set_device", "q4_stream_create", "q4_stream_destroy", "q4_set_stream",
+    "q4_status_string", "q4_last_error", "q4_set_device", "q4_stream_create", "q4_stream_create_masked", "q4_stream_destroy", "q4_set_stream",
     "q4_get_stream", "q4_stream_synchronize", "q4_device_synchronize", "q4_malloc", "q4_free", "q4_memcpy_h2d",
     "q4_memcpy_d2h", "q4_memset", "q4_rmsnorm", "q4_matmul_f16", "q4_matmul_q4", "q4_qkv_matvec", "q4_ffn_matvec_silu",
     "q4_rope_rotation", "q4_multi_head_attention", "q4_copy_embedding", "q4_convert_fp16_to_fp32", "q4_argmax",
@@ -58,7 +58,7 @@ SYMBOLS = [
     "build_sampler", "destroy_sampler", "random_u32", "random_f32", "q4_sample", "q4_build_transformer",
     "q4_free_transformer", "q4_set_quiet", "q4_transformer_new", "q4_transformer_delete", "q4_transformer_config",
     "q4_transformer_state", "q4_transformer_weights", "q4_sampler_new", "q4_sampler_delete", "q4_reset_sequence",
-    "q4_shared_pos", "q4_handoff_status", "q4_shared_token", "q4_get_logits", "q4_get_kv_row", "q4_get_logits_array", "q4_generate",
+    "q4_shared_pos", "q4_handoff_status", "q4_handoff_timeouts", "q4_shared_token", "q4_get_logits", "q4_get_kv_row", "q4_get_logits_array", "q4_generate",
     "q4_generate_ids", "q4_chat", "q4_softmax_f32", "compute_perplexity", "q4_get_dataset_perplexity",
     "q4_parse_dataset_and_compute_perplexity", "q4_perplexity_ids", "q4_tokenizer_new", "q4_tokenizer_delete",
     "q4_tokenizer_encode", "q4_tokenizer_decode", "q4_tokenizer_max_token_length", "q4_main", "q4_parse_args",
@@ -90,6 +90,7 @@ def lib():
     L.q4_status_string.argtypes = [i]
     L.q4_last_error.restype = C.c_char_p
     L.q4_stream_create.argtypes = [C.POINTER(vp)]
+    L.q4_stream_create_masked.argtypes = [C.POINTER(vp), i]
     L.q4_stream_destroy.argtypes = [vp]
     L.q4_set_stream.argtypes = [vp]
     L.q4_set_stream.restype = None
@@ -300,7 +301,9 @@ class Transformer:
         self.h = L.q4_transformer_new(path.encode(), int(perplexity), C.byref(st))
         if not self.h:
             raise Q4Error("build_transformer failed: %s %s" % (L.q4_status_string(st.value).decode(), L.q4_last_error().decode()))
-        self.config = L.q4_transformer_config(self.h).contents
+        # a COPY of the header: the C struct lives inside the Transformer and dies with close(); readers of
+        # `config` (bench.py prints it after closing) must never see freed memory
+        self.config = Config.from_buffer_copy(L.q4_transformer_config(self.h).contents)
         self.state = L.q4_transformer_state(self.h)
         self.weights = L.q4_transformer_weights(self.h)
         self.sampler = L.q4_sampler_new(self.config.vocab_size, temperature, topp, seed)

@@ -4,10 +4,8 @@
 // coalesced. Pass 1 scores -> LDS (fp32, rounded through fp16 like the reference's `att`, :167), block max / exp /
 // sum (:373-396), pass 2 probabilities (rounded through fp16, :400) times V (:311). Scores never leave the CU.
 //
-// The same body serves the stand-alone kernel (attention_kernel) and the attention role of the fused launch
-// (layer_attn.hip, FUSED = true): there the block requests the cached rows of positions < pos at entry -- while the
-// QKV blocks of the same launch are still streaming their weights --, waits for its head's q / k / v producers, fetches
-// q and the row of position pos with sc1 loads, and publishes its output write-through for the o-proj blocks.
+// The same body serves the stand-alone kernel (attention_kernel) and the attention role of the fused attention -> o-proj
+// launch (layer_attn.hip, FUSED = 2), which publishes its output write-through for the o-proj blocks of the same launch.
 #pragma once
 #include "gemv_q4.h"
 
@@ -38,12 +36,12 @@ struct AttArgs {
 };
 
 // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
-// FUSED: 0 stand-alone; 1 attention role of the QKV -> attention -> o-proj launch (waits for the head's q / k / v granules, publishes
-// its output as granules); 2 attention role of the attention -> o-proj launch (inputs from the previous launch, publishes granules)
+// FUSED: 0 stand-alone; 2 attention role of the attention -> o-proj launch (inputs from the previous launch, output published as
+// data-tagged granules for the o-proj blocks of the same launch)
 template <int LPR, int U, int NW, int FUSED>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
-    constexpr bool WAIT_IN = FUSED == 1, PUB = FUSED != 0;
+    constexpr bool PUB = FUSED != 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
     if (!FUSED && a.dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,9 +63,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     if (!FUSED && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
-    // context <= `group` positions (rows past the position are not requested at all). FUSED: the row of the current
-    // position does not exist yet -- it follows after the hand-off
-    const int ready = WAIT_IN ? size - 1 : size;
+    // context <= `group` positions (rows past the position are not requested at all)
+    const int ready = size;
     u32x4 kv0[U], vv0[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -79,42 +76,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
             vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)t * kv_dim);
         }
     }
-    u32x4 qv;
-    if (WAIT_IN) {
-        // q and the k / v rows of the current position arrive as granules from the head's QKV blocks of this launch:
-        // head_size/2 = 64 granules per vector, one per lane of wave 0, polled until all three vectors carry the tag
-        // (these 12 lines are polled by this block only)
-        unsigned* hand = reinterpret_cast<unsigned*>(sc + a.lds_scores);     // [3][64] dwords: q, k row, v row of this head
-        if (wave == 0) {
-            const unsigned gi = (unsigned)h * (head_size / 2) + lane;
-            const unsigned per_mat = (unsigned)(a.kv_dim / 2);                // granules per vector (dim == kv_dim here)
-            unsigned i = 0;
-            for (;; i++) {
-                const u32x2v gq = load_granule(ho.sub, gi), gk = load_granule(ho.sub, per_mat + gi), gv = load_granule(ho.sub, 2 * per_mat + gi);
-                const bool ok = gq[1] == ho.tag && gk[1] == ho.tag && gv[1] == ho.tag;
-                if (__all(ok)) { hand[lane] = gq[0]; hand[64 + lane] = gk[0]; hand[128 + lane] = gv[0]; break; }
-                if (i >= POLL_LIMIT) { if (lane == 0) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-#ifdef Q4_PROFILING
-            if (ho.stamp && lane == 0) *ho.stamp = wall_clock64();
-#endif
-        }
-        __syncthreads();
-        qv = reinterpret_cast<const u32x4*>(hand)[sub];
-        if (size - 1 < group) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int t = wave * R + row + u * stride;
-                if (t == size - 1) {
-                    kv0[u] = reinterpret_cast<const u32x4*>(hand + 64)[sub];
-                    vv0[u] = reinterpret_cast<const u32x4*>(hand + 128)[sub];
-                }
-            }
-        }
-    } else {
-        qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
-    }
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
 
     // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
     float wmax = -INFINITY;
@@ -128,7 +90,6 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
                 kv[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim);
-                if (WAIT_IN && tc == size - 1) kv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 64)[sub];   // this launch's row
             }
         }
 #pragma unroll
@@ -181,7 +142,6 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
                 const int t = g0 + wave * R + row + u * stride;
                 const int tc = t < size ? t : size - 1;
                 vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
-                if (WAIT_IN && tc == size - 1) vv[u] = reinterpret_cast<const u32x4*>(sc + a.lds_scores + 128)[sub];
             }
         }
 #pragma unroll
@@ -238,6 +198,9 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
                 s2[k] = s;
             }
             const h2 hh = {(f16_t)s2[0], (f16_t)s2[1]};
+#ifdef Q4_PROFILING
+            if (!ho.mute)
+#endif
             store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, as_u(hh), ho.tag);
             *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + tid * 2) = as_u(hh);
         }
@@ -479,6 +442,9 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
             const unsigned lo = combine_partials<true>(oh, partials + (size_t)h * nsp * rec, head_size, nsp, 2 * tid);
             const unsigned hi = combine_partials<true>(oh, partials + (size_t)h * nsp * rec, head_size, nsp, 2 * tid + 1);
             const unsigned data = lo | (hi << 16);
+#ifdef Q4_PROFILING
+            if (!ho.mute)
+#endif
             store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, data, ho.tag);
         }
     } else {

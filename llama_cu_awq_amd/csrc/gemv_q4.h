@@ -65,26 +65,31 @@ struct GemvArgs {
     unsigned long long* dbg;   // ABL == 3 only: per-wave s_memtime stamps
     const float2* rope_table;  // [seq_len][head_size/2] (cos, sin) built with the reference's formula; null: compute
     int early;                 // waves in the first `early` slots of a SIMD issue their weight loads before the staging ends
+    unsigned* bump;            // QKV: epoch word of the FOLLOWING attention + o-proj launch, advanced once by block (0, 0)
 };
 
-// In-launch hand-off (layer_attn.hip: QKV -> attention -> o-proj as ONE launch) with data-tagged granules: a vector
+// In-launch hand-off (layer_attn.hip: attention -> o-proj as ONE launch) with data-tagged granules: a vector
 // crosses CUs as 8-byte {two halves, tag} words, each written by ONE write-through (sc1) store, so a word is either old or
 // complete and carries its own validity -- no flag, no drain, no arrival counter on the producer side (measured: sc1
 // payload -> s_waitcnt vmcnt(0) -> returning atomic cost every producer block 1.7 us at its end). The tag is the launch's
-// epoch (a device word read at entry, bumped by the launch's last block), so stale granules of earlier launches never
-// match. Consumers put their weight loads in flight first, then poll with uncached (sc1) loads, bounded, with s_sleep.
+// epoch (a device word read at entry; it is bumped by the PRECEDING launch of the stream -- the fused QKV GEMV -- so every
+// block of the launch reads the same value whatever the dispatch order or timing), so stale granules of earlier launches
+// never match. Consumers put their weight loads in flight first, then poll with uncached (sc1) loads, bounded, with s_sleep.
 // Polls must stay off shared lines: an uncached poll lands on the memory channel of its address, and since a wave's loads
 // return in order, 160 blocks polling two shared cache lines stalled every weight stream of the launch (the later QKV
 // blocks ended 4-10 us late, tools/timeline_block.py). Here a line is polled by at most a handful of blocks.
 // (MI355X_MICROARCH.md: "handoff-1to1 ... data-tagged granules", R2.) ROLE_NONE compiles to the stand-alone kernel.
-constexpr int ROLE_NONE = 0, ROLE_PRODUCER = 1, ROLE_CONSUMER = 2;
+constexpr int ROLE_NONE = 0, ROLE_CONSUMER = 2;
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 struct Handoff {
     unsigned tag;          // this launch's tag (epoch + 1; zeroed buffers never match)
-    u32x2v* pub;           // producer: granule vector(s) to publish into (QKV: [3][N/2]; attention: [dim/2])
+    u32x2v* pub;           // producer (attention role): granule vector to publish into ([dim/2])
     const u32x2v* sub;     // consumer: granule vector to read (o-proj: the attention output, [K/2])
     int sentinel;          // consumer: granule polled first (staggered over the blocks: few pollers per line)
     unsigned* error;       // set to 1 when a bounded poll ran out (results are garbage then; the host reports it)
+    bool dead;             // the error word was already set at entry (an earlier launch timed out and the host has not cleared the
+                           // state yet): results are void anyway, so nobody spins again -- a long queue of launches behind a failure drains at once
+    bool mute;             // profiling build: this attention block does not publish (provokes a real time-out, tests/prof_cases.py)
     unsigned long long* stamp;   // profiling build: wall clock right after the wait
 };
 constexpr unsigned POLL_LIMIT = 1u << 20;   // ~0.25 us per poll: give up after ~0.3 s instead of hanging the GPU
@@ -157,7 +162,6 @@ struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL, int KS, bool HALF, int ROLE>
 __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned vbx, const unsigned vby, const Handoff& ho) {
     static_assert(ROLE == ROLE_NONE || (KS == 1 && ABL != 3), "hand-off roles: no K split, no time stamps");
-    static_assert(ROLE != ROLE_PRODUCER || MODE == MODE_QKV, "producer epilogue: QKV");
     static_assert(!HALF || (KS == 1 && COLS % 2 == 0), "shared half slot: no K split, column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
@@ -182,6 +186,10 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     // grouped-query attention: k and v have kv_dim < dim columns; the launch grid is sized for q, surplus blocks leave
     const int N = (MODE == MODE_QKV && mat0 != 0 && a.N_kv > 0) ? a.N_kv : a.N;
     if (MODE == MODE_QKV && (int)(vbx * (blockDim.x >> 6)) * COLS >= N) return;
+    // the next launch of the stream (attention -> o-proj, layer_attn.hip) tags its hand-off granules with this word: advanced
+    // here, one launch ahead, so that every block of that launch reads the same value (stream order, not dispatch order)
+    if (MODE == MODE_QKV && a.bump != nullptr && vbx == 0 && vby == 0 && tid == 0)
+        __hip_atomic_fetch_add(a.bump, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ABL == 3) { ts[0] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }   // [6]: 100 MHz, same on every XCD
 
@@ -237,7 +245,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
                 const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
                 xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
                 if (g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag) break;
-                if (tries >= POLL_LIMIT / 4) { ok = false; break; }
+                if (tries >= POLL_LIMIT / 4 || ho.dead) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -357,14 +365,14 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     }
     if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers' granules
         static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
-        if (tid == 0) {            // one lane polls ONE granule (spread over lines: few pollers per line) ...
+        if (tid == 0 && !ho.dead) {   // one lane polls ONE granule (spread over lines: few pollers per line) ...
             unsigned i = 0;
             while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
             if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         // ... then the block reads the whole vector; every granule validates itself
-        if (!load_x_granules()) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!load_x_granules() && !ho.dead) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef Q4_PROFILING
         if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();
 #endif
@@ -506,29 +514,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             }
             r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
-        if (ROLE == ROLE_PRODUCER) {
-#ifdef Q4_PROFILING
-            if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();     // math done, publishing starts
-#endif
-            // The block's 2 x 16 consecutive halves (its pairs' first and second halves; all of one head: the launcher
-            // checks head_size/2 % (2 * waves) == 0) are gathered in LDS. They go to their ordinary destination (q, the KV
-            // cache row) as plain 16-byte stores, and to the hand-off vector as 16 granules from ONE store instruction.
-            uint16_t* hbuf = reinterpret_cast<uint16_t*>(smem + (size_t)NUNITS * 16 + TS * 512 + (size_t)NUNITS * 4 + 16);
-            const int nwv = blockDim.x >> 6;                 // pairs per block = 2 * nwv
-            if (writer) hbuf[(row >> 1) * (2 * nwv) + wave * 2 + (row & 1)] = f2h(r);
-            __syncthreads();
-            const int p0 = (int)(vbx * nwv * 2);            // first pair of the block
-            const int head0 = p0 / hp, i0 = p0 - head0 * hp;
-            const int e0 = head0 * a.head_size + i0;         // first element of segment 0 in the output vector
-            if ((int)tid < 2 * nwv) {                        // one granule (2 halves) per lane: nwv per segment
-                const int seg = tid / nwv, k = tid - seg * nwv;
-                const unsigned data = *reinterpret_cast<const unsigned*>(hbuf + seg * (2 * nwv) + 2 * k);
-                store_granule(ho.pub + (size_t)mat0 * (N / 2) + (e0 + seg * hp) / 2 + k, data, ho.tag);
-                *reinterpret_cast<unsigned*>(out + e0 + seg * hp + 2 * k) = data;
-            }
-        } else {
-            if (writer && n < N) out[n] = f2h(r);
-        }
+        if (writer && n < N) out[n] = f2h(r);
     }
     if (ABL == 3 && a.dbg != nullptr && lane == 0) {
         ts[7] = __builtin_readcyclecounter();

@@ -1,0 +1,116 @@
+// layer_attn.h -- MultiHeadAttention (llama2_q4.cu:320) and the output projection with residual add (:323) as ONE
+// launch (fusion level 3, the default).
+//
+// Every launch of the decode step carries ~3-4 us that are not streaming (boundary, kernel arguments, first-data latency,
+// the x chain); attention and o-proj are the two latency-bound launches of a layer, so they share one: blocks [0, natt) are
+// the attention role -- one block per head, or per (head, chunk) in the split-context bins, exactly the stand-alone kernels'
+// bodies in 8-wave blocks --, the rest are the o-proj role (gemv_q4_body, 8 waves), which puts its weights in flight at entry,
+// polls ONE granule of the attention output, then reads the vector (every 8-byte {two halves, tag} granule validates itself
+// against the launch's epoch) and runs the dot products. The attention blocks publish with one store instruction per head
+// and never wait.
+//
+// What the protocol rests on:
+//  * forward progress: consumers wait only for producers, producers wait for nobody, and the launcher admits the form only
+//    when EVERY block of the grid can be resident at once (occupancy x the stream's CUs >= blocks, attention_oproj_form);
+//    no dispatch order is assumed. Otherwise the layer runs the stand-alone launches.
+//  * the tag is the value of the model's epoch word at entry + 1. The word is advanced by the PRECEDING launch of the stream
+//    (the fused QKV GEMV, gemv_q4.h `bump`), never by this one: all blocks read the same value, whatever their timing.
+//  * every wait is a bounded poll; one that runs out sets the model's sticky error word, which the token loops turn into a
+//    clean retry at fusion level 1 (q4_runtime.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "attention.h"
+
+namespace q4 {
+
+constexpr int LA_WAVES = 8;          // 512-thread blocks for both roles (16-wave o-proj blocks -- 64 of them -- lost 13-20 us per token)
+
+struct AttOprojArgs {
+    GemvArgs oproj;
+    AttArgs att;
+    SplitArgs split;
+    unsigned* sync;                  // hand-off words of the model (sync layout: q4_internal.h)
+    unsigned nheads, natt, no;       // heads, attention blocks (heads, or heads x chunks), o-proj blocks
+    unsigned long long* dbg;         // profiling build: [block][4] wall-clock stamps (entry, after the wait, end, role)
+    int mute;                        // profiling build: the attention blocks do not publish (a real time-out for tests/prof_cases.py)
+};
+
+// ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3: one block per (head, 128 / 256
+// positions), merged by each head's last block. LPR = lanes per cache row of a head (head_size / 8).
+template <int LPR, int ATT>
+struct AttShape { static constexpr int U = (ATT == 0 || ATT == 2 ? 128 : 256) / (LA_WAVES * (64 / LPR)); };
+
+template <int SLOTS, bool HALF, int ATT, int LPR>
+__global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const AttOprojArgs a) {
+    constexpr int NW = LA_WAVES;
+    constexpr int U = AttShape<LPR, ATT>::U;
+    static_assert(U >= 1, "rows in flight");
+    const unsigned b = blockIdx.x;
+    Handoff ho = {};
+    ho.error = a.sync + SYNC_ERROR;
+    // one 8-byte load: [0] the error word, [1] the epoch
+    const unsigned long long ee = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.sync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ho.tag = (unsigned)(ee >> 32) + 1u;
+    ho.dead = (unsigned)ee != 0u;
+#ifdef Q4_PROFILING
+    ho.mute = a.mute != 0;
+#endif
+    u32x2v* g_att = reinterpret_cast<u32x2v*>(a.sync + SYNC_GRANULES);
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = b < a.natt ? 1 : 2; }
+    ho.stamp = a.dbg ? a.dbg + b * 4 + 1 : nullptr;
+#endif
+    if (b < a.natt) {
+        ho.pub = g_att;
+        if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2>(a.att, (int)b, ho);
+        else attention_split_body<LPR, U, true, NW>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
+    } else {
+        const unsigned j = b - a.natt;
+        ho.sub = g_att;
+        ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);   // last granule of head j % heads
+        gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
+    }
+#ifdef Q4_PROFILING
+    if (a.dbg && threadIdx.x == 0) a.dbg[b * 4 + 2] = wall_clock64();
+#endif
+}
+
+// one translation unit per head size (layer_attn_h64.hip, layer_attn.hip, layer_attn_h256.hip)
+typedef int (*AttOprojLaunch)(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);
+int launch_attention_oproj_h64(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);
+int launch_attention_oproj_h128(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);
+int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);
+
+// slots_kind: 0 = K in two k-slots, 1 = three with a shared half slot, 2 = four. With max_blocks_per_cu != nullptr the call
+// only reports how many blocks of this instantiation fit a CU (occupancy query) and launches nothing.
+#define Q4_AO_DISPATCH(LPR)                                                                                              \
+    {                                                                                                                     \
+        auto go = [&](auto kernel) -> int {                                                                               \
+            if (max_blocks_per_cu) {                                                                                      \
+                int n = 0;                                                                                                \
+                Q4_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)block.x, smem));                     \
+                *max_blocks_per_cu = n;                                                                                   \
+                return Q4_OK;                                                                                             \
+            }                                                                                                             \
+            Q4_LAUNCH(kernel, grid, block, smem, a);                                                                      \
+            Q4_LAUNCH_CHECK();                                                                                            \
+            return Q4_OK;                                                                                                 \
+        };                                                                                                                \
+        switch (slots_kind * 4 + att) {                                                                                   \
+            case 0: return go(attention_oproj_kernel<2, false, 0, LPR>);                                                  \
+            case 1: return go(attention_oproj_kernel<2, false, 1, LPR>);                                                  \
+            case 2: return go(attention_oproj_kernel<2, false, 2, LPR>);                                                  \
+            case 3: return go(attention_oproj_kernel<2, false, 3, LPR>);                                                  \
+            case 4: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                   \
+            case 5: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                   \
+            case 6: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                   \
+            case 7: return go(attention_oproj_kernel<3, true, 3, LPR>);                                                   \
+            case 8: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                  \
+            case 9: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                  \
+            case 10: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
+            case 11: return go(attention_oproj_kernel<4, false, 3, LPR>);                                                 \
+        }                                                                                                                 \
+        return Q4_ERR_UNSUPPORTED_SIZE;                                                                                   \
+    }
+
+}  // namespace q4

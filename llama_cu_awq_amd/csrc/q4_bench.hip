@@ -16,7 +16,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
         case 1: return q4_matmul_q4(s->hb, s->xb, &L->wq_gate, dim, hidden, 0, -1, nullptr);
         case 2: return q4_matmul_q4(s->xb, s->hb, &L->wq_down, hidden, dim, 1, -1, nullptr);
         case 3: return launch_qkv_fused(s->q, s->key_cache, s->value_cache, s->x, L->rms_att_weight, &L->wq_q, &L->wq_k,
-                                        &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s));
+                                        &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s), nullptr);
         case 4: return q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr);
         case 5: return q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f);
         case 6: return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
@@ -79,7 +79,7 @@ extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, c
             case 1: rc = q4_matmul_q4(s->hb, s->xb, &L->wq_gate, dim, hidden, 0, -1, nullptr); break;
             case 2: rc = q4_matmul_q4(s->xb, s->hb, &L->wq_down, hidden, dim, 1, -1, nullptr); break;
             case 3: rc = launch_qkv_fused(s->q, s->key_cache, s->value_cache, s->x, L->rms_att_weight, &L->wq_q, &L->wq_k,
-                                          &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s)); break;
+                                          &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s), nullptr); break;
             case 4: rc = q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr); break;
             case 5: rc = q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f); break;
             case 6: rc = q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads,

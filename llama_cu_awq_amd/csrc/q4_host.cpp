@@ -166,39 +166,57 @@ double q4_generate(Transformer* transformer, struct Tokenizer* tokenizer, Sample
         fprintf(stderr, "something is wrong, expected at least 1 prompt token\n");
         exit(EXIT_FAILURE);
     }
-    long start = time_in_ms();
-    int next;
-    int token = prompt_tokens[0];
-    int pos = 0;
     RunState* state = &transformer->state;
-    die_on(q4_reset_sequence(state, prompt_tokens, num_prompt_tokens));            // :461-463
-    int queued = 0;
-    while (pos < steps) {
-        // step `pos` is queued behind step pos-1 before the host waits for step pos-1's token (reference: sync, then
-        // launch, :468-470) -- same device order, the GPU never idles between tokens; greedy steps inside one bin go out
-        // Q4_MULTI_STEPS at a time
-        if (pos >= queued) {
-            const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &transformer->config, sampler);
-            die_on(q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
-            queued = pos + k;
+    const unsigned long long rng0 = sampler->rng_state;
+    int timed_tokens = 0;
+    double time = 0.0;
+    for (int attempt = 0;; attempt++) {
+        long start = time_in_ms();
+        int next;
+        int token = prompt_tokens[0];
+        int pos = 0;
+        die_on(q4_reset_sequence(state, prompt_tokens, num_prompt_tokens));            // :461-463
+        int queued = 0, group_start = 0;
+        unsigned long long group_rng = sampler->rng_state;
+        bool stopped = false;
+        while (pos < steps) {
+            // step `pos` is queued behind step pos-1 before the host waits for step pos-1's token (reference: sync, then
+            // launch, :468-470) -- same device order, the GPU never idles between tokens; greedy steps inside one bin go out
+            // Q4_MULTI_STEPS at a time
+            if (pos >= queued) {
+                const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &transformer->config, sampler);
+                group_start = pos;
+                group_rng = sampler->rng_state;
+                die_on(q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &transformer->config, state, &transformer->weights, 0, sampler));
+                queued = pos + k;
+            }
+            die_on(q4_wait_pos(state, pos));                                           // :468
+            if (pos > 0) {
+                next = q4_shared_token(state, pos);                                    // output token of the previous iteration
+                if (next >= transformer->config.vocab_size) next = 0;                  // :474
+                const char* piece = q4_tokenizer_decode(tokenizer, token, next);
+                safe_printf(piece);
+                if (next == eos_token) { stopped = true; break; }
+                token = next;
+            }
+            pos++;
         }
-        die_on(q4_wait_pos(state, pos));                                           // :468
-        if (pos > 0) {
-            next = q4_shared_token(state, pos);                                    // output token of the previous iteration
-            if (next >= transformer->config.vocab_size) next = 0;                  // :474
-            const char* piece = q4_tokenizer_decode(tokenizer, token, next);
-            safe_printf(piece);
-            if (next == eos_token) break;
-            token = next;
+        printf("\n");
+        long end = time_in_ms();
+        if (stopped) {   // one coin per executed step as in the reference (sampler.h:45): undo the draws of the group's surplus steps
+            sampler->rng_state = group_rng;
+            for (int i = group_start; i <= pos; i++) (void)random_f32(&sampler->rng_state);
         }
-        pos++;
+        time = (end - start) / 1000.0;
+        timed_tokens = pos - 1;
+        if (q4_handoff_status(state) == Q4_OK) break;
+        // a bounded in-launch wait ran out: the text above is invalid. The library has cleared its hand-off state and dropped
+        // to fusion level 1 (no in-launch waits): say so and generate again, once
+        if (attempt > 0) die_on(Q4_ERR_HIP);
+        printf("\n[%s -- generating again]\n", q4_last_error());
+        sampler->rng_state = rng0;
     }
-    printf("\n");
-    long end = time_in_ms();
-    double time = (end - start) / 1000.0;
-    int timed_tokens = pos - 1;
     printf("\nachieved tok/s: %f. Tokens: %d, seconds: %g\n", timed_tokens / time, timed_tokens, time);   // :489
-    die_on(q4_handoff_status(state));          // a bounded in-launch wait that ran out invalidates the run: say so and exit
     free(prompt_tokens);
     if (timed_tokens_out) *timed_tokens_out = timed_tokens;
     if (seconds_out) *seconds_out = time;
@@ -261,6 +279,10 @@ void q4_chat(Transformer* transformer, struct Tokenizer* tokenizer, Sampler* sam
             if (next == eos_token) {
                 user_turn = 1;
                 printf("\n");
+                if (q4_handoff_status(state)) {   // the turn just printed came out of a timed-out in-launch wait: say so, stop
+                    printf("\n%s\n", q4_last_error());
+                    break;
+                }
             } else if (user_idx > num_prompt_tokens) {
                 const char* piece = q4_tokenizer_decode(tokenizer, token, next);
                 safe_printf(piece);
@@ -270,7 +292,7 @@ void q4_chat(Transformer* transformer, struct Tokenizer* tokenizer, Sampler* sam
         pos++;
     }
     printf("\n");
-    q4_stream_synchronize();
+    if (q4_handoff_status(state)) printf("\n%s\n", q4_last_error());
     free(prompt_tokens);
 }
 

@@ -60,22 +60,24 @@ static inline QGeom make_geom(int K, int N) {
 // ---- internal launchers shared by the API layer and the network (all enqueue on g_stream) ----
 struct GemvTune { int cols; int waves; int early; };   // columns per wave, waves per block, early-bird wave slots per SIMD
 
-// fused layer kernels (validated against the unfused chain in tests/test_fusion_gpu.py)
+// fused layer kernels (validated against the unfused chain in tests/test_forward_gpu.py::test_fused_equals_unfused_bits)
+// bump: epoch word of the attention -> o-proj launch that follows in the stream (advanced once by this launch), or null
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w,
                      const QWeight* qw, const QWeight* kw, const QWeight* vw, int dim, int kv_dim, long long loff,
-                     const int* pPos, int head_size, float rope_theta, const float2* rope_table);
+                     const int* pPos, int head_size, float rope_theta, const float2* rope_table, unsigned* bump);
 const float2* rope_table_of(const RunState* s);   // this model's table (q4_runtime.hip), null if none
 int rope_table_build(float2** out, int seq_len, int head_size, float theta);   // (cos,sin) table for the fused QKV epilogue
 int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                      int num_heads, int head_size, int kv_mul, int max_seq_len, const int* pPos, float* scratch,
                      size_t scratch_bytes, unsigned* arrive);   // arrive: n_heads zeroed counters (split-context merge by the last block) or null
-// QKV -> attention -> o-proj as one launch (layer_attn.hip); `sync`: attention_block_sync_words() zeroed words owned by the model
-size_t attention_block_sync_words(int dim, int n_heads);
-bool attention_block_supported(int dim, int kv_dim, int head_size, int seq_len_bin, int split_min);
-int launch_attention_block(q4_half* x, q4_half* xb, q4_half* q, q4_half* key_cache, q4_half* value_cache, const q4_half* rms_w,
-                           const QWeight* wq, const QWeight* wk, const QWeight* wv, const QWeight* wo, int dim, int n_heads,
-                           long long loff, const int* pPos, float rope_theta, const float2* rope_table, int seq_len_bin,
-                           unsigned* sync);
+// attention -> o-proj as one launch (layer_attn.h). Hand-off words of a model (unsigned), zeroed at build and by
+// q4_reset_sequence: [SYNC_ERROR] flag of a timed-out wait and [SYNC_EPOCH] launch epoch (advanced by the fused QKV launch) in
+// ONE aligned 8-byte word, [SYNC_ARRIVE .. +n_heads) arrival counters of the split-context merge, [SYNC_GRANULES ..) dim/2
+// granules {two halves, tag}
+enum { SYNC_ERROR = 0, SYNC_EPOCH = 1, SYNC_ARRIVE = 128, SYNC_MAX_HEADS = 512, SYNC_GRANULES = 1024 };
+extern int g_ao_mute;
+size_t attention_sync_words(int dim);
+void attention_oproj_forget_stream(hipStream_t s);
 int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int seq_len_bin, bool have_scratch, size_t scratch_bytes,
                          int split_min, int split_chunk);   // >= 0: the fused attention + o-proj launch covers this case
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
@@ -83,7 +85,7 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
                            float* scratch, size_t scratch_bytes, int split_min, int split_chunk);
 extern int g_att_chunk;
 extern int g_att_split_min;
-extern int g_la_early;
+extern int g_ao_guard;
 extern int g_multi_steps;
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,

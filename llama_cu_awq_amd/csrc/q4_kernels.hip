@@ -225,7 +225,7 @@ static int fill_geom(GemvArgs& a, int K, int N) {
 
 int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, const q4_half* rms_w, const QWeight* qw,
                      const QWeight* kw, const QWeight* vw, int dim, int kv_dim, long long loff, const int* pPos,
-                     int head_size, float rope_theta, const float2* rope_table) {
+                     int head_size, float rope_theta, const float2* rope_table, unsigned* bump) {
     if (kv_dim > dim || (kv_dim & 7)) return Q4_ERR_ARG;
     GemvArgs a = {};
     int rc = fill_geom(a, dim, dim);
@@ -237,6 +237,7 @@ int launch_qkv_fused(q4_half* q, q4_half* kc, q4_half* vc, const q4_half* x, con
     a.rope = head_size > 0; a.head_size = head_size > 0 ? head_size : 2; a.rope_theta = rope_theta;
     a.rope_table = head_size > 0 ? rope_table : nullptr;   // [seq_len][head_size/2] for THIS model, or null: compute
     a.early = g_tune[TUNE_QKV].early;
+    a.bump = bump;
     return launch_gemv_qkv(a, g_tune[TUNE_QKV].cols, g_tune[TUNE_QKV].waves);
 }
 
@@ -271,7 +272,8 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind >= 0 && kind < TUNE_COUNT) g_tune[kind].early = slots;
     if (kind == 6) g_att_8wave = slots;
     if (kind == 7) g_multi_steps = slots;
-    if (kind == 4) g_la_early = slots;      // fused attention-block launch: early birds of the QKV role
+    if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
+    if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
 }
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }

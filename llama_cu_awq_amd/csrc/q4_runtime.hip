@@ -18,6 +18,7 @@ int g_fusion = 3;
 int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
+static int g_handoff_timeouts = 0;     // timed-out in-launch waits seen by q4_handoff_status since the library was loaded
 char g_last_error[512] = "";
 hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
@@ -35,7 +36,7 @@ struct Slabs {
     void* shared = nullptr;
     void* logits_array = nullptr;
     float2* rope_table = nullptr;   // [seq_len][head_size/2] (cos, sin), lives exactly as long as the Transformer
-    unsigned* sync = nullptr;       // hand-off words of the fused attention-block launch (n_heads + 3), zero between launches
+    unsigned* sync = nullptr;       // hand-off words of the attention -> o-proj launch (layout: q4_internal.h SYNC_*)
 };
 static std::map<const Transformer*, Slabs> g_slabs;
 // the network entry points take (Config, RunState, TransformerWeights), not the Transformer: tables are found by RunState
@@ -97,8 +98,27 @@ int q4_stream_create(q4_stream_t* out) {
     *out = (q4_stream_t)s;
     return Q4_OK;
 }
+// A stream restricted to the first `n_cus` compute units (hipExtStreamCreateWithCUMask): lets a host run replicas side by
+// side on one GPU, and lets the tests run the in-launch hand-offs with fewer resident blocks than a whole device offers.
+int q4_stream_create_masked(q4_stream_t* out, int n_cus) {
+    int dev = 0, total = 0;
+    Q4_HIP(hipGetDevice(&dev));
+    Q4_HIP(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cus < 1 || n_cus > total) return Q4_ERR_ARG;
+    uint32_t mask[16] = {};
+    const int words = (total + 31) / 32;
+    if (words > 16) return Q4_ERR_ARG;
+    // CU bits are interleaved over the XCDs in the mask (bit i = CU i / 8 of XCD i % 8 on gfx950): taking the first n bits
+    // spreads the stream over all XCDs
+    for (int i = 0; i < n_cus; i++) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s;
+    Q4_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    *out = (q4_stream_t)s;
+    return Q4_OK;
+}
 int q4_stream_destroy(q4_stream_t s) {
     if ((hipStream_t)s == g_stream) g_stream = nullptr;
+    attention_oproj_forget_stream((hipStream_t)s);
     Q4_HIP(hipStreamDestroy((hipStream_t)s));
     return Q4_OK;
 }
@@ -124,7 +144,20 @@ int q4_memset(void* dst, int value, size_t bytes) {
     return Q4_OK;
 }
 
-void q4_set_fusion(int level) { g_fusion = level < 0 ? 0 : level > 3 ? 3 : level; q4_reset_graphs(); }
+// 0: the reference's 1:1 kernel sequence; 1: fused rmsnorm / RoPE / SiLU epilogues (five launches per layer); 3: attention ->
+// o-proj as one launch on top of that (default). Level 2 (QKV -> attention -> o-proj as one launch) was measured slower than
+// level 1 in round 2 and removed in round 3: the value selects level 1.
+void q4_set_fusion(int level) {
+    g_fusion = level <= 0 ? 0 : level >= 3 ? 3 : 1;
+    q4_reset_graphs();
+    for (auto& kv : g_sync_by_state) {     // no stale epoch / granules across a change of launch sequence
+        auto it = g_sync_words.find(kv.first);
+        if (it != g_sync_words.end() && it->second > SYNC_EPOCH && g_stream) {
+            hipMemsetAsync(kv.second + SYNC_EPOCH, 0, (it->second - SYNC_EPOCH) * sizeof(unsigned), g_stream);
+            hipStreamSynchronize(g_stream);
+        }
+    }
+}
 int q4_get_fusion(void) { return g_fusion; }
 void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
 void q4_set_quiet(int quiet) { g_quiet = quiet; }
@@ -319,9 +352,16 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     g_slabs[t] = slabs;
     if (rc) { q4_free_transformer(t); return rc; }
     if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
-    const size_t sync_words = attention_block_sync_words(p->dim, p->n_heads);
+    const size_t sync_words = attention_sync_words(p->dim);
     if (hipMalloc((void**)&slabs.sync, sync_words * sizeof(unsigned)) == hipSuccess) {
-        hipMemset(slabs.sync, 0, sync_words * sizeof(unsigned));
+        // zeroed on the launch stream and waited for: nothing else orders a null-stream memset before the first launch on a
+        // non-blocking g_stream when the caller starts with q4_run_transformer instead of q4_reset_sequence
+        if (hipMemsetAsync(slabs.sync, 0, sync_words * sizeof(unsigned), g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            hipDeviceSynchronize();
+            hipMemset(slabs.sync, 0, sync_words * sizeof(unsigned));
+            hipDeviceSynchronize();
+        }
         g_slabs[t] = slabs;
         g_sync_by_state[&t->state] = slabs.sync;
         g_sync_words[&t->state] = sync_words;
@@ -415,16 +455,15 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
         // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
         const long long loff = (long long)l * p->seq_len * kv_dim;
-        if (g_fusion == 2 && sync && attention_block_supported(dim, kv_dim, head_size, seq_len_bin, g_att_split_min)) {
-            // :300-323 in ONE launch: QKV blocks, attention heads and o-proj blocks hand over inside the launch (layer_attn.hip)
-            Q4_UNLESS(7, launch_attention_block(x, s->xb, s->q, s->key_cache, s->value_cache, L->rms_att_weight, &L->wq_q, &L->wq_k,
-                                                &L->wq_v, &L->wq_o, dim, p->n_heads, loff, pPos, p->rope_theta, rope_table,
-                                                seq_len_bin, sync));
-        } else {
+        const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
+        // :320-323 as ONE launch where the geometry, the bin and the stream's CUs admit it (layer_attn.h); the fused QKV launch in
+        // front of it advances the launch's epoch word
+        const bool ao = g_fusion >= 3 && sync &&
+                        attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0;
         if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
-                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table));
+                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table, ao ? sync + SYNC_EPOCH : nullptr));
         } else {
             Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_att_weight, dim));                                      // :300
             if (dim == kv_dim) {
@@ -436,19 +475,14 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
-        const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
-        if (g_fusion >= 3 && sync &&
-            attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0) {
-            // :320-323 in ONE launch: the attention heads hand their output to the o-proj blocks inside the launch
+        if (ao) {
             Q4_UNLESS(6, launch_attention_oproj(x, s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, dim, kv_dim, p->n_heads,
                                                 pPos, seq_len_bin, sync, (float*)s->att, att_bytes, g_att_split_min, g_att_chunk));
         } else {
         Q4_UNLESS(2, launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, kv_mul,
                                       seq_len_bin, pPos, (float*)s->att,
-                                      (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half),
-                                      sync && p->n_heads <= 512 ? sync + 128 : nullptr));              // :320
+                                      att_bytes, sync && p->n_heads <= SYNC_MAX_HEADS ? sync + SYNC_ARRIVE : nullptr));   // :320
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
-        }
         }
         if (g_fusion) {
             Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
@@ -636,8 +670,8 @@ int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_toke
     Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
     if (unsigned* sync = sync_words_of(s)) {     // hand-off words are zero between launches; also after a failed one
         auto it = g_sync_words.find(s);
-        if (it != g_sync_words.end() && it->second > 32)
-            Q4_HIP(hipMemsetAsync(sync + 32, 0, (it->second - 32) * sizeof(unsigned), g_stream));
+        if (it != g_sync_words.end() && it->second > SYNC_EPOCH)   // the error word [0] stays until q4_handoff_status reads it
+            Q4_HIP(hipMemsetAsync(sync + SYNC_EPOCH, 0, (it->second - SYNC_EPOCH) * sizeof(unsigned), g_stream));
     }
     Q4_HIP(hipStreamSynchronize(g_stream));
     s->shared_data->pos = 0;                                                       // :462
@@ -660,21 +694,29 @@ int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p
     if (graph_bin(pos + 1, p, &b0) != graph_bin(pos + k, p, &b1)) return 1;
     return k;
 }
-// The in-launch hand-offs of fusion level 2 spin for a bounded time; a spin that ran out sets a sticky device flag
-// (results from then on are invalid). Synchronises the stream and reports it.
+// The in-launch hand-offs of fusion level 3 (attention -> o-proj, layer_attn.h) spin for a bounded time; a spin that ran out
+// sets the model's error word: everything computed since is invalid. Synchronises the stream and reports it ONCE: the word,
+// the epoch, the counters and the granules are cleared, and the library drops to fusion level 1 (no in-launch waits) for
+// the rest of the process, so the caller can simply redo the sequence -- the token loops of this library do exactly that.
 int q4_handoff_status(const RunState* s) {
     Q4_HIP(hipStreamSynchronize(g_stream));
     unsigned* sync = sync_words_of(s);
     auto it = g_sync_words.find(s);
     if (!sync || it == g_sync_words.end()) return Q4_OK;
     unsigned flag = 0;
-    Q4_HIP(hipMemcpy(&flag, sync, sizeof(flag), hipMemcpyDeviceToHost));
+    Q4_HIP(hipMemcpy(&flag, sync + SYNC_ERROR, sizeof(flag), hipMemcpyDeviceToHost));
     if (flag) {
-        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 2)");
+        Q4_HIP(hipMemsetAsync(sync, 0, it->second * sizeof(unsigned), g_stream));
+        Q4_HIP(hipStreamSynchronize(g_stream));
+        g_handoff_timeouts++;
+        if (g_fusion >= 3) { g_fusion = 1; q4_reset_graphs(); }
+        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 3); state cleared, continuing at fusion level 1");
+        if (!g_quiet) fprintf(stderr, "llama2_q4: %s\n", g_last_error);
         return Q4_ERR_HIP;
     }
     return Q4_OK;
 }
+int q4_handoff_timeouts(void) { return g_handoff_timeouts; }
 // Wait until the device has published position >= pos (argmax_kernel / sample_scan_kernel write the token, fence, then
 // SharedData::pos -- "unblocks the CPU", gpu_kernels.h:490). Spins on the pinned word; falls back to the stream state
 // so that a failed launch cannot hang the host.
@@ -720,40 +762,55 @@ double q4_generate_ids(Transformer* t, Sampler* sampler, const int* prompt_token
                        int* out_tokens, int* timed_tokens_out, double* seconds_out) {
     if (num_prompt_tokens < 1) return -1.0;
     if (steps <= 0 || steps > t->config.seq_len) steps = t->config.seq_len;        // :690
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    int pos = 0, queued = 0;
-    if (q4_reset_sequence(&t->state, prompt_tokens, num_prompt_tokens)) return -1.0;
-    while (pos < steps) {
-        // the reference synchronises and then launches step `pos` (:468-470); here the launch goes out first, queued
-        // behind step pos-1, and the host then waits for step pos-1's token -- same device order, no idle gap per token.
-        // Greedy steps inside one bin go out Q4_MULTI_STEPS at a time (one graph replay); a stop at EOS leaves at most
-        // Q4_MULTI_STEPS - 1 surplus steps behind, which the next q4_reset_sequence discards.
-        if (pos >= queued) {
-            const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &t->config, sampler);
-            if (q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
-            queued = pos + k;
+    const unsigned long long rng0 = sampler->rng_state;
+    for (int attempt = 0;; attempt++) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        int pos = 0, queued = 0, group_start = 0;
+        unsigned long long group_rng = sampler->rng_state;   // sampler state in front of the group of steps queued last
+        if (q4_reset_sequence(&t->state, prompt_tokens, num_prompt_tokens)) return -1.0;
+        bool stopped = false;
+        while (pos < steps) {
+            // the reference synchronises and then launches step `pos` (:468-470); here the launch goes out first, queued
+            // behind step pos-1, and the host then waits for step pos-1's token -- same device order, no idle gap per token.
+            // Greedy steps inside one bin go out Q4_MULTI_STEPS at a time (one graph replay); a stop at EOS leaves at most
+            // Q4_MULTI_STEPS - 1 surplus steps behind, which the next q4_reset_sequence discards.
+            if (pos >= queued) {
+                const int k = q4_steps_that_fit(pos, num_prompt_tokens, steps, &t->config, sampler);
+                group_start = pos;
+                group_rng = sampler->rng_state;
+                if (q4_run_transformer_steps(pos, k, pos >= num_prompt_tokens - 1, &t->config, &t->state, &t->weights, 0, sampler)) return -1.0;
+                queued = pos + k;
+            }
+            if (q4_wait_pos(&t->state, pos)) return -1.0;                              // :468
+            if (pos > 0) {
+                int next = t->state.shared_data->tokens[pos];                          // :473
+                if (next >= t->config.vocab_size) next = 0;                            // :474
+                if (next == 2) { stopped = true; break; }                              // eos_token, :477
+            }
+            pos++;
         }
-        if (q4_wait_pos(&t->state, pos)) return -1.0;                              // :468
-        if (pos > 0) {
-            int next = t->state.shared_data->tokens[pos];                          // :473
-            if (next >= t->config.vocab_size) next = 0;                            // :474
-            if (next == 2) break;                                                  // eos_token, :477
+        clock_gettime(CLOCK_MONOTONIC, &t1);                                           // :485, taken where the reference takes it
+        if (stopped) {
+            // the reference has drawn one coin per run_transformer call, steps 0..pos (sampler.h:45); a multi-step group drew
+            // for its surplus steps too: put the stream back to exactly pos + 1 draws so a reused Sampler continues like the reference's
+            sampler->rng_state = group_rng;
+            for (int i = group_start; i <= pos; i++) (void)random_f32(&sampler->rng_state);
         }
-        pos++;
+        const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        const int timed_tokens = pos - 1;                                              // :488
+        if (q4_handoff_status(&t->state)) {     // a timed-out in-launch wait: the library is at fusion level 1 now, state cleared
+            if (attempt == 0) { sampler->rng_state = rng0; continue; }                 // redo the whole sequence once
+            return -1.0;
+        }
+        if (out_tokens) {
+            const int n = (pos < steps ? pos : steps) + 1;
+            for (int i = 0; i < n && i < Q4_MAX_SEQ_LEN; i++) out_tokens[i] = t->state.shared_data->tokens[i];
+        }
+        if (timed_tokens_out) *timed_tokens_out = timed_tokens;
+        if (seconds_out) *seconds_out = secs;
+        return secs > 0 ? timed_tokens / secs : 0.0;
     }
-    hipStreamSynchronize(g_stream);
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-    const int timed_tokens = pos - 1;                                              // :488
-    if (q4_handoff_status(&t->state)) return -1.0;                                 // a timed-out hand-off: fail loudly
-    if (out_tokens) {
-        const int n = (pos < steps ? pos : steps) + 1;
-        for (int i = 0; i < n && i < Q4_MAX_SEQ_LEN; i++) out_tokens[i] = t->state.shared_data->tokens[i];
-    }
-    if (timed_tokens_out) *timed_tokens_out = timed_tokens;
-    if (seconds_out) *seconds_out = secs;
-    return secs > 0 ? timed_tokens / secs : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -787,13 +844,19 @@ float q4_perplexity_ids(Transformer* t, Sampler* sampler, const int* tokens_with
     RunState* state = &t->state;
     if (!state->logits_array || num_tokens < 1) return -1.0f;
     if (num_tokens >= config->seq_len) num_tokens = config->seq_len - 1;           // :68-72
-    if (q4_reset_sequence(state, tokens_with_bos, num_tokens + 1)) return -1.0f;   // :76-78
-    // the input tokens are all known: the steps are queued back to back (the device advances its own position) and the
-    // host synchronises once, where the reference calls cudaDeviceSynchronize after every step (:81)
-    for (int pos = 0; pos < num_tokens; pos++)
-        if (q4_run_transformer_at(pos, 0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
-    if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                        // :81
-    if (q4_handoff_status(state)) return -1.0f;                                    // a timed-out in-launch wait: fail loudly
+    const unsigned long long rng0 = sampler->rng_state;
+    for (int attempt = 0;; attempt++) {
+        if (q4_reset_sequence(state, tokens_with_bos, num_tokens + 1)) return -1.0f;   // :76-78
+        // the input tokens are all known: the steps are queued back to back (the device advances its own position) and the
+        // host synchronises once, where the reference calls cudaDeviceSynchronize after every step (:81)
+        for (int pos = 0; pos < num_tokens; pos++)
+            if (q4_run_transformer_at(pos, 0, config, state, &t->weights, 1, sampler)) return -1.0f;   // :80
+        if (hipDeviceSynchronize() != hipSuccess) return -1.0f;                        // :81
+        if (!q4_handoff_status(state)) break;
+        // a timed-out in-launch wait: the library has dropped to fusion level 1 and cleared its state; redo the pass once
+        if (attempt > 0) return -1.0f;
+        sampler->rng_state = rng0;
+    }
     float* logits_arr = (float*)malloc((size_t)num_tokens * config->vocab_size * sizeof(float));
     if (q4_get_logits_array(t, num_tokens, logits_arr)) { free(logits_arr); return -1.0f; }   // :88-89
     float pplx = compute_perplexity(tokens_with_bos + 1, logits_arr, num_tokens, config->vocab_size);   // :91

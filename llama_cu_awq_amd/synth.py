@@ -43,6 +43,11 @@ GEOMETRIES = {
     "head128_k5120": (5120, 1408, 1, 40, 40, 512, 300, 10000.0),
     "head128_gqa": (2560, 3584, 2, 20, 4, 512, 700, 1000000.0),   # grouped-query (kv_mul 5) with a fused attention + o-proj form
     "head64_long": (512, 1408, 2, 8, 4, 512, 1300, 10000.0),     # head 64, grouped-query, context past the split threshold
+    # the other head sizes / K widths of the attention -> o-proj launch: TinyLlama-1.1B's shape (head 64, GQA 8:1, K = 2048 in
+    # ONE k-slot), a head-256 model, and K = dim = 8192 in four k-slots with 70B-style GQA
+    "tinyllama": (2048, 5632, 2, 32, 4, 512, 1100, 10000.0),
+    "head256": (1024, 2816, 2, 4, 2, 512, 600, 10000.0),
+    "head128_k8192": (8192, 1408, 1, 64, 8, 512, 300, 1000000.0),
     # the sampler at production vocabulary sizes on a one-layer body: 32000 = the register/LDS path with 32 keys per
     # thread, 40000 = the global-memory fallback (> 32 x 1024 entries)
     "v32k": (64, 96, 1, 2, 2, 32000, 32, 10000.0),

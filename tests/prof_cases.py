@@ -77,3 +77,94 @@ def test_shared_half_slot_matches_the_full_slot_form(q4, orc, rng, K, N, kind):
     for o in outs:
         assert_close_f16(o, ref, max_ulp=2 if kind == "ffn" else 1, max_frac=0.10, what="%s half-slot" % kind)
     assert_close_f16(outs[0], outs[1], max_ulp=2 if kind == "ffn" else 1, max_frac=0.10, what="%s half vs full" % kind)
+
+
+def _model_file(name):
+    import os
+    geom = synth.GEOMETRIES[name]
+    path = os.path.join(os.environ.get("Q4_MODEL_DIR", "/tmp"), "llama2_q4_synth_%s_seed20240229.bin" % name)
+    if not (os.path.exists(path) and os.path.getsize(path) == synth.model_bytes(geom)):
+        synth.write_model(path, geom)
+    return path
+
+
+@pytest.mark.parametrize("model,n_cus,steps", [("7b", 32, 48), ("7b", 8, 48), ("head128", 8, 1060), ("head128", 3, 700)])
+def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, model, n_cus, steps):
+    """The attention -> o-proj launch on a CU-masked stream with the residency guard switched OFF (a knob of the profiling
+    build): 160-400 blocks on 3 / 8 / 32 CUs, so most o-proj blocks are dispatched only after earlier blocks have left. The
+    product never runs it that way (the guard falls back to the launch sequence, tests/test_baseline_configs_gpu.py); this
+    case shows what the guard protects against does not bite on this hardware either: work-groups are dispatched in index
+    order, producers come first and wait for nobody. No bounded poll may run out; bits equal fusion level 1 in the first bin,
+    the model's bound above it (split-context bins included for the small model)."""
+    import ctypes as C
+    L = q4.lib()
+    full = L.q4_get_stream()
+    path = _model_file(model)
+    outs = {}
+    cps = (3, 40, 47) if model == "7b" else (3, 127, 255, 511, 600, steps - 1)
+    try:
+        for lvl in (1, 3):
+            s = C.c_void_p()
+            q4.check(L.q4_stream_create_masked(C.byref(s), n_cus))
+            L.q4_set_stream(s)
+            L.q4_set_gemv_early(8, 0)          # guard off
+            L.q4_set_fusion(lvl)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in cps:
+                    q4.synchronize()
+                    got.append(t.logits().copy())
+            q4.check(L.q4_handoff_status(t.state))
+            assert L.q4_handoff_timeouts() == 0 and L.q4_get_fusion() == lvl
+            outs[lvl] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            t.close()
+            L.q4_set_stream(full)
+            q4.check(L.q4_stream_destroy(s))
+    finally:
+        L.q4_set_stream(full)
+        L.q4_set_gemv_early(8, 1)
+        L.q4_set_fusion(3)
+    for a, b, pos in zip(outs[1][0], outs[3][0], cps):
+        if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:
+            assert pos > 200, "token rings diverged early (%d)" % pos
+            break
+        if pos < 128:
+            assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), pos
+        else:
+            af, bf = a.astype(np.float64), b.astype(np.float64)
+            assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), pos
+
+
+def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_level_1(q4, tmp_path):
+    """A REAL time-out: the attention blocks of one launch do not publish (profiling knob), the o-proj blocks' bounded polls
+    run out and set the model's error word; launches queued behind it do not spin again (`dead`). q4_generate_ids must notice,
+    clear the state, drop to fusion level 1 and return the tokens of a clean run; q4_perplexity_ids likewise."""
+    L = q4.lib()
+    p = str(tmp_path / "head128.bin")
+    synth.write_model(p, "head128", seed=7)
+    prompt = [1, 5, 9]
+    try:
+        L.q4_set_fusion(1)
+        t = q4.Transformer(p, perplexity=True)
+        want = t.generate_ids(prompt, 40)[0].copy()
+        ptoks = np.concatenate([[1], np.arange(3, 23)]).astype(np.int32)
+        want_ppl = t.perplexity_ids(ptoks)
+        L.q4_set_fusion(3)
+        assert np.array_equal(t.generate_ids(prompt, 40)[0], want)      # level 3, nothing sabotaged: same greedy ring (first bin)
+        assert L.q4_handoff_timeouts() == 0
+        L.q4_set_gemv_early(9, 1)                                       # the next attention -> o-proj launch is captured mute
+        got = t.generate_ids(prompt, 40)[0]
+        assert np.array_equal(got, want)
+        assert L.q4_handoff_timeouts() == 1 and L.q4_get_fusion() == 1
+        q4.check(L.q4_handoff_status(t.state))                          # reported once, state clean now
+        L.q4_set_fusion(3)
+        L.q4_set_gemv_early(9, 1)
+        ppl = t.perplexity_ids(ptoks)
+        assert ppl == want_ppl and L.q4_handoff_timeouts() == 2 and L.q4_get_fusion() == 1
+        t.close()
+    finally:
+        L.q4_set_gemv_early(9, 0)
+        L.q4_set_fusion(3)

@@ -14,7 +14,7 @@ from llama_cu_awq_amd import api, synth   # noqa: E402
 api.use_profiling_build()
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
 upto = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-fusion = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+fusion = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
     synth.write_model(path, model)
