@@ -200,6 +200,9 @@ def main():
             else:   # o-proj QWeight + residual in/out + the K and V rows of positions 0..pos of every kv head + q + output
                 avg_pos_ = p0_ + 1.5
                 nb_ = kb[4][1] + int((avg_pos_ + 1) * 2 * kv_dim * 2) + 2 * cfg.dim * 2
+            if cls == 32:       # two launches of this class per token (final rmsnorm, classifier): price the pair
+                a_ = 2.0 * a_
+                nb_ += 3 * cfg.dim * 2
             per_kernel[nm] = {"hip_event_us": round(a_, 3), "bytes": nb_, "GBps": round(nb_ / a_ / 1e3, 1),
                               "frac": round(nb_ / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_, "first_position": p0_}
         in_network[kb[0][0]] = round(net_avg, 3)

@@ -80,6 +80,8 @@ def lib():
     if _lib is not None:
         return _lib
     path = PROF_LIB_PATH if _use_prof else LIB_PATH
+    # tools/ab.py compares builds of the library inside one gpurun call (clocks differ from box to box by several per cent)
+    path = os.environ.get("Q4_LIB_OVERRIDE") or path
     if not os.path.exists(path):
         raise RuntimeError(
             "%s is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
@@ -90,7 +92,8 @@ def lib():
     L.q4_status_string.argtypes = [i]
     L.q4_last_error.restype = C.c_char_p
     L.q4_stream_create.argtypes = [C.POINTER(vp)]
-    L.q4_stream_create_masked.argtypes = [C.POINTER(vp), i]
+    if hasattr(L, "q4_stream_create_masked"):      # (older builds under tools/ab.py do not have it)
+        L.q4_stream_create_masked.argtypes = [C.POINTER(vp), i]
     L.q4_stream_destroy.argtypes = [vp]
     L.q4_set_stream.argtypes = [vp]
     L.q4_set_stream.restype = None

@@ -63,7 +63,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     if (!FUSED && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
-    // context <= `group` positions (rows past the position are not requested at all)
+    // context <= `group` positions (rows past the position are not requested at all: requesting the whole bin ahead of the
+    // position word, to save that dependent latency, was measured 22-31 us per token SLOWER at 7B -- the bytes cost more)
     const int ready = size;
     u32x4 kv0[U], vv0[U];
 #pragma unroll

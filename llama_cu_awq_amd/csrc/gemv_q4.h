@@ -57,6 +57,7 @@ struct GemvArgs {
     int K, N;               // input length, output columns (per matrix)
     int N_kv;               // QKV with grouped-query attention: columns of the k and v matrices (0: same as N)
     int pw4, pzh, sh, nslots;
+    int ku;                 // K split (KS > 1): uint4 units per k-part, a multiple of 4 (whole groups); part p owns units [p*ku, (p+1)*ku)
     int accum;              // PLAIN: out = half(float(out) + sum)
     long long loff;         // PLAIN: -1 = none. QKV: KV-cache layer offset (64-bit: 13B at 16K positions exceeds 2^31 halves)
     int rope;               // QKV: rotate q and k in the epilogue
@@ -149,8 +150,20 @@ __device__ __forceinline__ int early_rank() {
     return (int)(((id & 15u) << 2) | (id >> 4));
 }
 
-template <int MODE, int SLOTS, int COLS>
-struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
+template <int MODE, int SLOTS, int COLS, int KS = 1>
+struct LaunchTraits { static constexpr int MAX_THREADS = KS == 3 ? 768 : (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
+
+// LDS of one block: permuted x [rows][4][64] x 16 B, the x-only sums [rows][64], and `part` (rmsnorm chunk partials: one float
+// per 16-byte unit; K-split kernels only exchange a few totals there). K-split kernels carry one extra all-zero row: the idle
+// lanes of a part's last slot read it (their neighbours in LDS are the NEXT part's inputs, not padding).
+template <int SLOTS, int KS>
+struct LdsLayout {
+    static constexpr int TS = SLOTS * KS;
+    static constexpr int ROWS = KS > 1 ? TS + 1 : TS;
+    static constexpr int NUNITS = ROWS * 256;
+    static constexpr size_t XS = (size_t)NUNITS * 16, SX = (size_t)ROWS * 256, PART = KS > 1 ? 1024 : (size_t)NUNITS * 4;
+    static constexpr size_t BYTES = XS + SX + PART + 16;
+};
 
 // KS = 2 (PLAIN only): two waves share a column group, each takes SLOTS of the KS*SLOTS k-slots and the partial
 // totals meet in LDS. The N = dim projections (o, down) have only N/4 = 1024 column groups = one wave per SIMD, and a
@@ -166,30 +179,29 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
     static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
-    static_assert(KS == 1 || (KS == 2 && MODE == MODE_PLAIN && COLS == 4), "K split: plain GEMV, 4 columns");
-    constexpr int TS = SLOTS * KS;              // k-slots of the whole column (this wave handles SLOTS of them)
-    constexpr int NUNITS = TS * 256;            // 16-byte LDS units (zero padded past K)
+    static_assert(KS == 1 || ((KS == 2 || KS == 3) && MODE == MODE_PLAIN && COLS == 4 && !NORM), "K split: plain GEMV, 4 columns");
+    using Lds = LdsLayout<SLOTS, KS>;
+    constexpr int TS = Lds::ROWS;               // 64-unit rows staged in LDS: the column's k-slots (+ the zero row of a K split)
+    constexpr int NUNITS = Lds::NUNITS;         // 16-byte LDS units (zero padded past K)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* xs = reinterpret_cast<u32x4*>(smem);                                   // [SLOTS][4][64] permuted x
-    float* sx = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16);             // [TS][64] -(sum of the 32 x) * 2^-20
-    float* part = reinterpret_cast<float*>(smem + (size_t)NUNITS * 16 + TS * 512);   // [NUNITS] chunk partials / K-split exchange
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                                   // [TS][4][64] permuted x
+    float* sx = reinterpret_cast<float*>(smem + Lds::XS);                         // [TS][64] -(sum of the 32 x) * 2^-20
+    float* part = reinterpret_cast<float*>(smem + Lds::XS + Lds::SX);             // chunk partials / K-split exchange
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: column offsets stay in SGPRs
     const int nw = blockDim.x >> 6;
     const int wg = vbx * (nw / KS) + wave / KS;   // global column-group index
-    const int khalf = wave % KS;
-    const int sbase = khalf * SLOTS;            // first k-slot of this wave
+    const int khalf = wave % KS;                // which k-part of the column this wave sums
+    // K split: part p owns uint4 units [p * ku, (p + 1) * ku) -- balanced to whole quantisation groups, not to 64-unit slots
+    const unsigned ubase = KS > 1 ? (unsigned)(khalf * a.ku) : 0u;
+    const unsigned uend = KS > 1 ? (ubase + (unsigned)a.ku < (unsigned)a.pw4 ? ubase + (unsigned)a.ku : (unsigned)a.pw4) : (unsigned)a.pw4;
     const unsigned nchunks = (unsigned)a.K >> 3;            // real 8-half chunks
     const int mat0 = (MODE == MODE_QKV) ? vby : 0;
     // grouped-query attention: k and v have kv_dim < dim columns; the launch grid is sized for q, surplus blocks leave
     const int N = (MODE == MODE_QKV && mat0 != 0 && a.N_kv > 0) ? a.N_kv : a.N;
     if (MODE == MODE_QKV && (int)(vbx * (blockDim.x >> 6)) * COLS >= N) return;
-    // the next launch of the stream (attention -> o-proj, layer_attn.hip) tags its hand-off granules with this word: advanced
-    // here, one launch ahead, so that every block of that launch reads the same value (stream order, not dispatch order)
-    if (MODE == MODE_QKV && a.bump != nullptr && vbx == 0 && vby == 0 && tid == 0)
-        __hip_atomic_fetch_add(a.bump, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ABL == 3) { ts[0] = __builtin_readcyclecounter(); ts[6] = wall_clock64(); }   // [6]: 100 MHz, same on every XCD
 
@@ -286,8 +298,8 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     }
 #define Q4_ISSUE_SLOT(s)                                                                                          \
     {                                                                                                             \
-        const unsigned j = (sbase + (s)) * 64 + lane;                                                             \
-        const unsigned jj = j < (unsigned)a.pw4 ? j : (unsigned)a.pw4 - 1; /* tail lanes re-read the last unit */ \
+        const unsigned j = ubase + (s) * 64 + lane;                                                               \
+        const unsigned jj = j < uend ? j : uend - 1; /* tail lanes re-read the part's last unit */                \
         _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c++) {       \
             ZW[m][s][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4, colc[c] * a.pzh * 4, Q4_ZS_AUX); \
             SC[m][s][c] = __builtin_amdgcn_raw_buffer_load_b16(rs[m], (jj >> 2) * 2, colc[c] * a.sh * 2, Q4_ZS_AUX);  \
@@ -399,11 +411,17 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     for (int s = 0; s < SLOTS; s++) {
         const bool hs = HALF && s == SLOTS - 1;                 // shared half slot: both halves of the wave read units 0-31
         const unsigned lu = hs ? (lane & 31u) : lane;
+        unsigned j = ubase + s * 64 + lu;                       // the uint4 unit this lane multiplies in this slot
+        unsigned jx = j;                                        // ... and where its inputs sit in LDS
+        if (KS > 1) {                                           // past the part's end: the all-zero row (the unit was re-read, see above)
+            jx = j < uend ? j : (unsigned)((TS - 1) * 64);
+            j = j < uend ? j : uend - 1;
+        }
         u32x4 X[4];
+        const unsigned xrow = KS > 1 ? ((jx >> 6) << 8) + (jx & 63u) : (unsigned)((s * 4) << 6) + lu;
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[d] = xs[(((sbase + s) * 4 + d) << 6) + lu];
-        const float corr = sx[(sbase + s) * 64 + lu];
-        const unsigned j = (sbase + s) * 64 + lu;
+        for (int d = 0; d < 4; d++) X[d] = xs[xrow + (d << 6)];
+        const float corr = sx[KS > 1 ? jx : (unsigned)(s * 64) + lu];
         const unsigned zsh = ((j >> 2) & 7u) * 4u;
 #pragma unroll
         for (int m = 0; m < NMAT; m++)
@@ -451,10 +469,13 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         if constexpr (COLS == 4) {
             float tot = reduce4_rows(colsum[0][0], colsum[0][1], colsum[0][2], colsum[0][3]) * 1048576.f;   // 2^20, exact
             const int n = wg * 4 + row;
-            if (KS == 2) {                      // fixed order: lower k half + upper k half
+            if (KS > 1) {                       // fixed order: k-parts from the lowest up
                 if (writer) part[wave * 4 + row] = tot;
                 __syncthreads();
-                if (khalf == 0) tot += part[(wave + 1) * 4 + row];
+                if (khalf == 0) {
+                    tot += part[(wave + 1) * 4 + row];
+                    if (KS == 3) tot += part[(wave + 2) * 4 + row];
+                }
             }
             if (writer && khalf == 0 && n < N) {
                 float r = tot;
@@ -515,6 +536,11 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             r = (row & 2) ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
         }
         if (writer && n < N) out[n] = f2h(r);
+        // the next launch of the stream (attention -> o-proj, layer_attn.h) tags its hand-off granules with this word: advanced
+        // here, one launch ahead, so that every block of that launch reads the same value (stream order, not dispatch order).
+        // At the very end: a memory operation in front of the weight loads costs the kernel its per-slot waits (+0.5 us measured)
+        if (a.bump != nullptr && vbx == 0 && vby == 0 && tid == 0)
+            __hip_atomic_fetch_add(a.bump, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (ABL == 3 && a.dbg != nullptr && lane == 0) {
         ts[7] = __builtin_readcyclecounter();
@@ -525,7 +551,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
 }
 
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
-__global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
+__global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THREADS)) gemv_q4_kernel(const GemvArgs a) {
     gemv_q4_body<MODE, SLOTS, COLS, NORM, ABL, KS, HALF, ROLE_NONE>(a, blockIdx.x, blockIdx.y, Handoff{});
 }
 
@@ -541,10 +567,12 @@ static inline int cu_count() {
 // host-side dispatch -------------------------------------------------------------------------------
 extern int g_ablate;
 extern int g_half_tail; // 1: shared half slot where the shape allows it (13B: K = 5120)
-extern int g_ksplit;    // 1: split K over two waves for the plain GEMV (default), 0: one wave per column group
+extern int g_ksplit;    // long-K plain GEMV: 2 / 3 waves per column group, 0: one
+extern int g_ks3_waves; // block width of the three-way split
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
 static int launch_one(const GemvArgs& a0, int waves) {
-    if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS>::MAX_THREADS / 64;
+    if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THREADS / 64;
+    waves -= waves % KS;
     const int cols_per_block = COLS * (waves / KS);
     dim3 grid(divUp(a0.N, cols_per_block), MODE == MODE_QKV ? 3 : 1);
     GemvArgs a = a0;
@@ -554,8 +582,7 @@ static int launch_one(const GemvArgs& a0, int waves) {
         const int waves_per_cu = (int)((size_t)grid.x * grid.y * waves / (size_t)cu_count());
         a.early |= (waves_per_cu <= 12 ? 0 : waves_per_cu <= 16 ? 4 : 8) << 8;
     }
-    constexpr int TS = SLOTS * KS;
-    const size_t smem = (size_t)TS * 256 * 16 + (size_t)TS * 512 + (size_t)TS * 256 * 4 + 16;
+    const size_t smem = LdsLayout<SLOTS, KS>::BYTES;
     if (smem > 64 * 1024) {   // long-K split kernels stage up to 32768 inputs: opt in to the CU's 160 KB once
         static bool opted = false;
         if (!opted) {

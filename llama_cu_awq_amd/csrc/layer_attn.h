@@ -11,8 +11,8 @@
 //
 // What the protocol rests on:
 //  * forward progress: consumers wait only for producers, producers wait for nobody, and the launcher admits the form only
-//    when EVERY block of the grid can be resident at once (occupancy x the stream's CUs >= blocks, attention_oproj_form);
-//    no dispatch order is assumed. Otherwise the layer runs the stand-alone launches.
+//    when the consumers alone cannot fill the stream's CUs (occupancy x CUs > o-proj blocks, attention_oproj_form): a slot
+//    is then always open to a producer; no dispatch order is assumed. Otherwise the layer runs the stand-alone launches.
 //  * the tag is the value of the model's epoch word at entry + 1. The word is advanced by the PRECEDING launch of the stream
 //    (the fused QKV GEMV, gemv_q4.h `bump`), never by this one: all blocks read the same value, whatever their timing.
 //  * every wait is a bounded poll; one that runs out sets the model's sticky error word, which the token loops turn into a

@@ -52,7 +52,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     s.launch = head_size == 64 ? launch_attention_oproj_h64 : head_size == 128 ? launch_attention_oproj_h128 :
                head_size == 256 ? launch_attention_oproj_h256 : nullptr;
     if (!s.launch || !(kv_dim > 0 && dim % kv_dim == 0 && (dim % (LA_WAVES * 4)) == 0)) return s;
-    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 512 ? 128 : 256);
+    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 1024 ? 128 : 256);
     const int nsp = divUp(seq_len_bin, chunk);
     const bool split = seq_len_bin >= split_min && have_scratch && n_heads <= SYNC_MAX_HEADS &&
                        (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
@@ -74,8 +74,10 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     if (s.att < 0) return -1;
     const size_t smem = ao_smem(s, head_size, seq_len_bin);
     if (smem > 64 * 1024) return -1;
-    // Residency guard: the o-proj blocks spin on the attention blocks of the same launch. That is placement-independent only
-    // if every block of the grid can be resident at once; then nobody waits for a block that is not running yet.
+    // Residency guard. Only the o-proj blocks wait, and only for attention blocks, which wait for nobody. Whatever order the
+    // dispatcher picks, the launch cannot wedge as long as the waiting blocks alone cannot fill the stream's CUs: a slot is then
+    // always left for an attention block, and every attention block that runs ends. (All blocks resident at once is the common
+    // case; the split-context form of the last bin has more attention blocks than slots -- they queue behind each other.)
     const unsigned blocks = (unsigned)(n_heads * s.nsp + dim / (LA_WAVES * 4));
     static std::map<unsigned long long, int> occupancy;     // per instantiation and LDS size (the query is a host call)
     const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 4 + s.att) << 32) | smem;
@@ -86,7 +88,8 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
         it = occupancy.insert({key, n}).first;
     }
     const int per_cu = it->second;
-    if (g_ao_guard && (long long)per_cu * stream_cu_count() < (long long)blocks) return -1;
+    const long long waiters = dim / (LA_WAVES * 4);
+    if (g_ao_guard && (long long)per_cu * stream_cu_count() < waiters + 1) return -1;
     return s.att;
 }
 

@@ -15,7 +15,8 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 // launch shapes (columns per wave, waves per block); tuned on MI355X, see DESIGN.md
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
 int g_ablate = 0;
-int g_ksplit = 1;
+int g_ksplit = 2;
+int g_ks3_waves = 6;
 int g_half_tail = 1;
 int g_att_chunk = 0;         // positions per split-attention block: 128, 256, or 0 = 128 up to bin 512 and 256 above (measured)
 int g_att_8wave = 0;         // head 128, bins 256 / 512: 8 waves x 8 loads in flight (1, the fused launch's shape) or 16 waves x 4
@@ -279,6 +280,7 @@ void q4_set_gemv_early(int kind, int slots) {
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 void q4_set_gemv_tune(int kind, int cols, int waves) {
     if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }
+    if (kind == 5 && (waves == 3 || waves == 6 || waves == 9 || waves == 12)) g_ks3_waves = waves;   // block width of the three-way K split
 }
 #endif
 
@@ -359,7 +361,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     dim3 block(ATT_NW * 64);
     // long context: one block per (head, 256-position chunk); merged by each head's last block (arrive != nullptr: the
     // model's counters) or by a second launch (see attention_split_kernel)
-    const int want = g_att_chunk ? g_att_chunk : (max_seq_len <= 512 ? 128 : 256);
+    const int want = g_att_chunk ? g_att_chunk : (max_seq_len <= 1024 ? 128 : 256);
     const int chunk = want == 128 && head_size == 128 ? 128 : 256;
     const int nsp = divUp(max_seq_len, chunk);
     const bool split = max_seq_len >= g_att_split_min && scratch != nullptr && (head_size == 64 || head_size == 128 || head_size == 256) &&

@@ -273,7 +273,16 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     carve_weights(cur, w, p);
 
     // checkpoint_init_weights :172-202 (same tensor order: embedding, wcls, final norm; per layer q,k,v,o,up,gate,down,norms)
+    // staging buffer = the largest single read (the reference sizes it max(vocab, hidden) * dim halves, :176, which a q/o
+    // matrix outgrows when dim > 4 * max(vocab, hidden))
     size_t scratch_size = (size_t)(p->vocab_size > p->hidden_dim ? p->vocab_size : p->hidden_dim) * p->dim * sizeof(q4_half);
+    {
+        size_t wb, zb, sb;
+        qweight_bytes(p->dim, p->dim, &wb, &zb, &sb);
+        if (wb > scratch_size) scratch_size = wb;
+        qweight_bytes(p->hidden_dim, p->dim, &wb, &zb, &sb);
+        if (wb > scratch_size) scratch_size = wb;
+    }
     void* scratch = nullptr;
     if (hipHostMalloc(&scratch, scratch_size, hipHostMallocDefault) != hipSuccess) scratch = nullptr;
     bool scratch_pinned = scratch != nullptr;
