@@ -4,17 +4,12 @@ namespace q4 {
 int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
 #define Q4_CASE(S, C) if (slots == S && cols == C) return launch_one<MODE_PLAIN, S, C, false>(a, waves);
     const int slots = pick_slots(a.nslots);
-    if ((g_ksplit && a.nslots >= 5) || a.nslots > 8) {   // long-K (down projection): KS waves per column group (gemv_q4.h, KS)
-        const int ks = g_ksplit == 3 && a.nslots <= 18 ? 3 : 2;
+    if ((g_ksplit && a.nslots >= 5) || a.nslots > 8) {   // long-K (down projection): two waves per column group (gemv_q4.h, KS)
+        // (three balanced parts were measured too, in 3 / 6 / 12-wave blocks: 7B 7.5-8.4 us against 6.6, 13B 13.1-15.7 against 12.0)
+        const int ks = 2;
         GemvArgs b = a;
         b.ku = (divUp(a.pw4, ks) + 3) & ~3;                    // whole quantisation groups per k-part
-        const int sh = divUp(b.ku, 64);                        // KS 2: up to 8 slots (K <= 32768, Llama-2-70B / CodeLlama-34B down projections)
-        if (ks == 3) {
-            if (waves % 3) waves = g_ks3_waves;
-#define Q4_KS3(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 3>(b, waves);
-            Q4_KS3(1) Q4_KS3(2) Q4_KS3(3) Q4_KS3(4) Q4_KS3(5) Q4_KS3(6)
-#undef Q4_KS3
-        }
+        const int sh = divUp(b.ku, 64);                        // up to 8 slots (K <= 32768, Llama-2-70B / CodeLlama-34B down projections)
 #define Q4_KS(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 2>(b, waves);
         Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4) Q4_KS(5) Q4_KS(6) Q4_KS(7) Q4_KS(8)
 #undef Q4_KS

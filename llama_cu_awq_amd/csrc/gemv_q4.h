@@ -151,7 +151,7 @@ __device__ __forceinline__ int early_rank() {
 }
 
 template <int MODE, int SLOTS, int COLS, int KS = 1>
-struct LaunchTraits { static constexpr int MAX_THREADS = KS == 3 ? 768 : (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
+struct LaunchTraits { static constexpr int MAX_THREADS = (ModeTraits<MODE>::NMAT * SLOTS * COLS >= 24) ? 256 : 512; };
 
 // LDS of one block: permuted x [rows][4][64] x 16 B, the x-only sums [rows][64], and `part` (rmsnorm chunk partials: one float
 // per 16-byte unit; K-split kernels only exchange a few totals there). K-split kernels carry one extra all-zero row: the idle
@@ -179,7 +179,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
     static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
-    static_assert(KS == 1 || ((KS == 2 || KS == 3) && MODE == MODE_PLAIN && COLS == 4 && !NORM), "K split: plain GEMV, 4 columns");
+    static_assert(KS == 1 || (KS == 2 && MODE == MODE_PLAIN && COLS == 4 && !NORM), "K split: plain GEMV, 4 columns");
     using Lds = LdsLayout<SLOTS, KS>;
     constexpr int TS = Lds::ROWS;               // 64-unit rows staged in LDS: the column's k-slots (+ the zero row of a K split)
     constexpr int NUNITS = Lds::NUNITS;         // 16-byte LDS units (zero padded past K)
@@ -472,10 +472,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             if (KS > 1) {                       // fixed order: k-parts from the lowest up
                 if (writer) part[wave * 4 + row] = tot;
                 __syncthreads();
-                if (khalf == 0) {
-                    tot += part[(wave + 1) * 4 + row];
-                    if (KS == 3) tot += part[(wave + 2) * 4 + row];
-                }
+                if (khalf == 0) tot += part[(wave + 1) * 4 + row];
             }
             if (writer && khalf == 0 && n < N) {
                 float r = tot;
@@ -567,8 +564,7 @@ static inline int cu_count() {
 // host-side dispatch -------------------------------------------------------------------------------
 extern int g_ablate;
 extern int g_half_tail; // 1: shared half slot where the shape allows it (13B: K = 5120)
-extern int g_ksplit;    // long-K plain GEMV: 2 / 3 waves per column group, 0: one
-extern int g_ks3_waves; // block width of the three-way split
+extern int g_ksplit;    // long-K plain GEMV: 2 waves per column group (default), 0: one
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL = 0, int KS = 1, bool HALF = false>
 static int launch_one(const GemvArgs& a0, int waves) {
     if (waves * 64 > LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THREADS) waves = LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THREADS / 64;

@@ -16,7 +16,6 @@ int launch_gemv_ffn(const GemvArgs& a, int cols, int waves);
 enum { TUNE_PLAIN_SMALL = 0, TUNE_PLAIN_BIG = 1, TUNE_QKV = 2, TUNE_FFN = 3, TUNE_COUNT = 4 };
 int g_ablate = 0;
 int g_ksplit = 2;
-int g_ks3_waves = 6;
 int g_half_tail = 1;
 int g_att_chunk = 0;         // positions per split-attention block: 128, 256, or 0 = 128 up to bin 512 and 256 above (measured)
 int g_att_8wave = 0;         // head 128, bins 256 / 512: 8 waves x 8 loads in flight (1, the fused launch's shape) or 16 waves x 4
@@ -280,7 +279,6 @@ void q4_set_gemv_early(int kind, int slots) {
 void q4_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 void q4_set_gemv_tune(int kind, int cols, int waves) {
     if (kind >= 0 && kind < TUNE_COUNT && waves >= 4 && waves <= 8) { g_tune[kind].cols = cols; g_tune[kind].waves = waves; }
-    if (kind == 5 && (waves == 3 || waves == 6 || waves == 9 || waves == 12)) g_ks3_waves = waves;   // block width of the three-way K split
 }
 #endif
 

@@ -459,16 +459,17 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
 
     Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
+    const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
+    // :320-323 as ONE launch where the geometry, the bin and the stream's CUs admit it (layer_attn.h); the launch in front of it
+    // (the fused QKV GEMV) advances its epoch word
+    const bool ao = g_fusion >= 3 && sync &&
+                    attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0;
+
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
         // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
         const long long loff = (long long)l * p->seq_len * kv_dim;
-        const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
-        // :320-323 as ONE launch where the geometry, the bin and the stream's CUs admit it (layer_attn.h); the fused QKV launch in
-        // front of it advances the launch's epoch word
-        const bool ao = g_fusion >= 3 && sync &&
-                        attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0;
         if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,

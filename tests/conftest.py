@@ -21,6 +21,7 @@ def q4():
     from llama_cu_awq_amd import api
     import ctypes as C
     L = api.lib()
+    api.DEFAULT_FUSION = L.q4_get_fusion()      # tests that change the level put this one back
     api.check(L.q4_set_device(0))
     s = C.c_void_p()
     api.check(L.q4_stream_create(C.byref(s)))

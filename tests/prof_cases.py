@@ -126,7 +126,7 @@ def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, mod
     finally:
         L.q4_set_stream(full)
         L.q4_set_gemv_early(8, 1)
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
     for a, b, pos in zip(outs[1][0], outs[3][0], cps):
         if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:
             assert pos > 200, "token rings diverged early (%d)" % pos
@@ -152,7 +152,7 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
         want = t.generate_ids(prompt, 40)[0].copy()
         ptoks = np.concatenate([[1], np.arange(3, 23)]).astype(np.int32)
         want_ppl = t.perplexity_ids(ptoks)
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
         assert np.array_equal(t.generate_ids(prompt, 40)[0], want)      # level 3, nothing sabotaged: same greedy ring (first bin)
         assert L.q4_handoff_timeouts() == 0
         L.q4_set_gemv_early(9, 1)                                       # the next attention -> o-proj launch is captured mute
@@ -160,11 +160,11 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
         assert np.array_equal(got, want)
         assert L.q4_handoff_timeouts() == 1 and L.q4_get_fusion() == 1
         q4.check(L.q4_handoff_status(t.state))                          # reported once, state clean now
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
         L.q4_set_gemv_early(9, 1)
         ppl = t.perplexity_ids(ptoks)
         assert ppl == want_ppl and L.q4_handoff_timeouts() == 2 and L.q4_get_fusion() == 1
         t.close()
     finally:
         L.q4_set_gemv_early(9, 0)
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)

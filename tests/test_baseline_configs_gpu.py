@@ -145,7 +145,7 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     split-context attention from bin 1024 on), then compare ONE more step with the restatement started from the GPU's
     own KV cache -- no 2000-step CPU run, and every cached position takes part in the compared step's attention."""
     L = q4.lib()
-    assert L.q4_get_fusion() == 3
+    assert L.q4_get_fusion() == q4.DEFAULT_FUSION
     t = q4.Transformer(m7b)
     m = orc.Model(m7b)
     toks, tps, timed, _ = t.generate_ids(PROMPT, target)          # positions 0 .. target-1 (graphs of 128 .. 2048)
@@ -207,7 +207,7 @@ def test_repeated_generations_are_identical_and_no_handoff_times_out(q4, m7b):
     """Soak of the default path (attention -> o-proj as one launch, in-launch hand-off): 50 `-n 256` generations must reproduce
     the first one's token ring, leave the hand-off error word clear and the library at fusion level 3."""
     L = q4.lib()
-    assert L.q4_get_fusion() == 3
+    assert L.q4_get_fusion() == q4.DEFAULT_FUSION
     before = L.q4_handoff_timeouts()
     t = q4.Transformer(m7b)
     ref = t.generate_ids(PROMPT, 256)[0].copy()
@@ -215,7 +215,7 @@ def test_repeated_generations_are_identical_and_no_handoff_times_out(q4, m7b):
         toks = t.generate_ids(PROMPT, 256)[0]
         assert np.array_equal(toks, ref), "token ring changed in run %d" % run
     q4.check(L.q4_handoff_status(t.state))
-    assert L.q4_handoff_timeouts() == before and L.q4_get_fusion() == 3
+    assert L.q4_handoff_timeouts() == before and L.q4_get_fusion() == q4.DEFAULT_FUSION
     t.close()
 
 
@@ -233,7 +233,7 @@ def test_masked_stream_falls_back_to_the_launch_sequence(q4, m7b, n_cus):
             if masked:
                 q4.check(L.q4_stream_create_masked(C.byref(s), n_cus))
                 L.q4_set_stream(s)
-            L.q4_set_fusion(3 if masked else 1)
+            L.q4_set_fusion(q4.DEFAULT_FUSION if masked else 1)
             t = q4.Transformer(m7b)
             t.reset(PROMPT)
             for pos in range(12):
@@ -247,6 +247,6 @@ def test_masked_stream_falls_back_to_the_launch_sequence(q4, m7b, n_cus):
                 q4.check(L.q4_stream_destroy(s))
     finally:
         L.q4_set_stream(full)
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
     # 8 CUs x 2 resident blocks < 160 blocks; at 32 CUs 64 < 160 as well: both run the launch sequence
     assert np.array_equal(outs["level1_full"], outs["level3_masked"])

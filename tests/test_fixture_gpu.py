@@ -44,4 +44,4 @@ def test_micro_model_against_committed_goldens(q4, fusion):
                 assert np.abs(gv.astype(np.float32) - exp["v"][layer, pos].astype(np.float32)).max() < 1e-4
         t.close()
     finally:
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)

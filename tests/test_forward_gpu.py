@@ -70,7 +70,7 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
         t.close()
         m.close()
     finally:
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
         L.q4_set_use_graphs(1)
 
 
@@ -105,7 +105,7 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
             outs[fusion] = (got, ring)
             t.close()
     finally:
-        L.q4_set_fusion(3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
     # levels 1 and 3 run the same device code; in the first bin also in the same shapes: identical bits up to position 127
     # (head 128; the stand-alone kernels of the other head sizes work with 16 waves there, the fused launch with 8).
     # From bin 256 on the fused launch's attention role works with 8 waves x 8 rows in flight, the stand-alone kernel with
@@ -191,7 +191,7 @@ def test_fused_equals_unfused_bits(q4, models, name):
         q4.synchronize()
         outs.append(t.logits().copy())
         t.close()
-    L.q4_set_fusion(3)
+    L.q4_set_fusion(q4.DEFAULT_FUSION)
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
 
 
@@ -268,7 +268,7 @@ def test_bench_in_network_times_the_products_own_launches(q4, models):
     try:
         assert t.bench_in_network(1 | 2 | 4 | 8 | 16, tokens=1)[3] == 5 * t.config.n_layers
     finally:
-        q4.lib().q4_set_fusion(3)
+        q4.lib().q4_set_fusion(q4.DEFAULT_FUSION)
     t.close()
 
 

@@ -48,41 +48,69 @@ for d in sorted(glob.glob(os.path.join(src, "trace_*"))):
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1]))[:8]:
         print("   %-90s %6d calls avg %8.3f us" % (k[:90], len(v), sum(v) / len(v)))
 
-KERNELS = {0: "gemv_q4_kernel<2", 2: "gemv_q4_kernel<0, 3", 3: "gemv_q4_kernel<1", 4: "gemv_q4_kernel<0, 2", 5: "gemv_f16_kernel", 6: "attention"}
-NAMES = {0: "ffn_rmsnorm_gate_up_silu_q4", 2: "gemv_q4_hidden_to_dim_accum (down)", 3: "qkv_rmsnorm_rope_q4", 4: "gemv_q4_oproj_accum", 5: "classifier_f16",
-         6: "attention, stand-alone one-block kernel (q4_multi_head_attention)"}
 
 
 def qweight_bytes(K, N):
     return ((K + 31) // 32 * 4) * N * 4 + (((K + 127) // 128 + 7) // 8) * N * 4 + ((K + 127) // 128) * N * 2
 
 
-d_, h_, v_ = 4096, 11008, 32000
-ALG = {0: 2 * qweight_bytes(d_, h_) + 2 * d_ * 2 + h_ * 2, 2: qweight_bytes(h_, d_) + h_ * 2 + 2 * d_ * 2, 3: 3 * qweight_bytes(d_, d_) + 2 * d_ * 2 + 3 * d_ * 2,
-       4: qweight_bytes(d_, d_) + d_ * 2 + 2 * d_ * 2, 5: v_ * d_ * 2 + d_ * 2 + v_ * 2, 6: None}
+GEOM = {"7b": (4096, 11008, 32000, 32), "13b": (5120, 13824, 32000, 40)}
+
+
+def algorithmic(kernel, model, ntok):
+    """algorithmic bytes per launch of a kernel of the decode network (weights + metadata + vectors in / out)"""
+    d, h, v, _ = GEOM[model]
+    if kernel.startswith("gemv_q4_kernel<2"):
+        return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
+    if kernel.startswith("gemv_q4_kernel<1"):
+        return 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2
+    if kernel.startswith("gemv_q4_kernel<0"):
+        return qweight_bytes(h, d) + h * 2 + 2 * d * 2
+    if kernel.startswith("gemv_f16_kernel"):
+        return v * d * 2 + d * 2 + v * 2
+    if kernel.startswith("attention_oproj_kernel"):
+        # o-proj QWeight + residual in / out + q + attention output + K and V rows of positions 0..pos, averaged over the
+        # positions this form serves in a -n ntok run (form = third template argument: 0 bin 128, 1 bin 256, 2 / 3 split bins)
+        m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel)
+        form = int(m.group(1)) if m else 0
+        lo, hi = {0: (0, 128), 1: (128, 256), 2: (256, 1024), 3: (1024, 2048)}[form]
+        hi = min(hi, ntok)
+        avg_rows = (lo + hi + 1) / 2.0
+        return int(qweight_bytes(d, d) + 4 * d * 2 + avg_rows * 2 * d * 2)
+    return None
+
+
 traffic = {}
-for kid, pat in KERNELS.items():
-    ent = {"kernel": NAMES[kid], "algorithmic_bytes_per_launch": ALG[kid]}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
+    m = re.match(r"pmc_(\w+)_(\d+)_FETCH_SIZE", os.path.basename(d))
+    if not m or not os.path.isdir(d):
+        continue
+    model, ntok = m.group(1), int(m.group(2))
+    per = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         vals = defaultdict(list)
-        for f in glob.glob(os.path.join(src, "pmc_k%d_%s" % (kid, c), "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(src, "pmc_%s_%d_%s" % (model, ntok, c), "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == c and pat in r["Kernel_Name"]:
+                if r["Counter_Name"] == c:
                     vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for k, v in vals.items():
-            ent.setdefault("per_kernel", {}).setdefault(k, {})[c + "_KB_avg"] = round(sum(v) / len(v), 2)
-            ent["per_kernel"][k]["dispatches"] = len(v)
-    tot = 0.0
-    for k, e in ent.get("per_kernel", {}).items():
+            per.setdefault(k, {})[c + "_KB_avg"] = round(sum(v) / len(v), 2)
+            per[k]["dispatches"] = len(v)
+    for k, e in per.items():
         e["traffic_bytes_per_launch"] = int(2 * 1024 * e.get("FETCH_SIZE_KB_avg", 0) + 1024 * e.get("WRITE_SIZE_KB_avg", 0))
-        tot += e["traffic_bytes_per_launch"]
-    if ent.get("per_kernel"):
-        ent["traffic_bytes_per_launch"] = int(tot)
-        if ALG[kid]:
-            ent["traffic_over_algorithmic"] = round(tot / ALG[kid], 4)
-    traffic[str(kid)] = ent
-    print(kid, json.dumps(ent)[:300])
-traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), 32 dispatches over the 32 layers' "
-                   "weights each (tools/prof_kernel.py <id> 32, 7B geometry). FETCH_SIZE on gfx950 tallies the 128-B requests of 16 B/lane "
-                   "streaming reads at 64 B (MI355X_MICROARCH.md, HBM section): doubled before comparing with byte counts.")
+        alg = algorithmic(k, model, ntok)
+        if alg:
+            e["algorithmic_bytes_per_launch"] = alg
+            e["traffic_over_algorithmic"] = round(e["traffic_bytes_per_launch"] / alg, 4)
+    traffic["%s_n%d" % (model, ntok)] = per
+    print(model, ntok, json.dumps(per)[:600])
+if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
+    for k, e in traffic["7b_n256"].items():
+        if k.startswith("gemv_q4_kernel<2"):
+            traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
+                            "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
+traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
+                   "product's own launch sequence (tools/prof_decode.py). FETCH_SIZE on gfx950 tallies the 128-B requests of 16 B/lane "
+                   "streaming reads at 64 B (MI355X_MICROARCH.md, HBM section): doubled before comparing with byte counts. Kernels that read "
+                   "narrower than 16 B per lane (attention merges, argmax) are outside that calibration.")
 json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)

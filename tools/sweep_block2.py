@@ -9,7 +9,7 @@ from llama_cu_awq_amd import api, synth   # noqa: E402
 
 api.use_profiling_build()
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
-levels = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 3, 2]
+levels = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 3]
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
     synth.write_model(path, model)
@@ -31,7 +31,6 @@ res = {}
 for rep in range(2):
     for fusion in levels:
         L.q4_set_fusion(fusion)
-        L.q4_set_gemv_early(4, 8 | (8 << 8))
         tr.generate_ids(prompt, 2048)
         t = [secs(n) for n in EDGES]
         per = [1e3 * t[0] / (EDGES[0] - 1)] + [1e3 * (t[i] - t[i - 1]) / (EDGES[i] - EDGES[i - 1]) for i in range(1, len(EDGES))]
