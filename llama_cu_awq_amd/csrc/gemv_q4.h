@@ -175,7 +175,7 @@ struct LdsLayout {
 template <int MODE, int SLOTS, int COLS, bool NORM, int ABL, int KS, bool HALF, int ROLE>
 __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned vbx, const unsigned vby, const Handoff& ho) {
     static_assert(ROLE == ROLE_NONE || (KS == 1 && ABL != 3), "hand-off roles: no K split, no time stamps");
-    static_assert(!HALF || (KS == 1 && COLS % 2 == 0), "shared half slot: no K split, column pairs");
+    static_assert(!HALF || COLS % 2 == 0, "shared half slot: column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
     static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
@@ -314,8 +314,8 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     const bool upper = lane >= 32u;
 #define Q4_ISSUE_HALF()                                                                                           \
     {                                                                                                             \
-        const unsigned jh = (SLOTS - 1) * 64 + (lane & 31u);                                                      \
-        const unsigned jj = jh < (unsigned)a.pw4 ? jh : (unsigned)a.pw4 - 1;                                      \
+        const unsigned jh = ubase + (SLOTS - 1) * 64 + (lane & 31u);                                              \
+        const unsigned jj = jh < uend ? jh : uend - 1;                                                            \
         _Pragma("unroll") for (int m = 0; m < NMAT; m++) _Pragma("unroll") for (int c = 0; c < COLS; c += 2) {    \
             const unsigned cw = upper ? (unsigned)colc[c + 1] : (unsigned)colc[c];                                \
             ZW[m][SLOTS - 1][c] = __builtin_amdgcn_raw_buffer_load_b32(rz[m], (jj >> 5) * 4 + cw * a.pzh * 4, 0, 0); \
