@@ -42,8 +42,13 @@ template <int LPR, int U, int NW, int FUSED>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr bool PUB = FUSED != 0;
+#ifdef Q4_PROFILING
+    constexpr bool STAMPS = true;          // profiling build: the fused role is stamped too (tools/timeline_attn.py)
+#else
+    constexpr bool STAMPS = !FUSED;
+#endif
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
-    if (!FUSED && a.dbg) ts[0] = __builtin_readcyclecounter();
+    if (STAMPS && a.dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red_max = reinterpret_cast<float*>(smem);         // [16]
     float* red_sum = red_max + 16;                           // [16]
@@ -59,25 +64,35 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     const q4_half* kh = a.key_cache + hoff;
     const q4_half* vh = a.value_cache + hoff;
     if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
-    const int size = *a.pPos + 1;
-    if (!FUSED && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
+    const int size = __builtin_amdgcn_readfirstlane(*a.pPos) + 1;     // wave-uniform by construction: descriptors below stay in SGPRs
+    if (STAMPS && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
     // context <= `group` positions (rows past the position are not requested at all: requesting the whole bin ahead of the
     // position word, to save that dependent latency, was measured 22-31 us per token SLOWER at 7B -- the bytes cost more)
-    const int ready = size;
+    // Request order = arrival order (a wave's loads return in order): q first, then every K row, then every V row. One head is
+    // one CU pulling (position + 1) x 512 B at ~26 GB/s (measured: 1.95 us at position 100, 3.2 us at 200, s_memtime stamps of
+    // tools/timeline_attn.py); the scores, the two softmax barriers and the exponentials run while the V rows are still landing.
+    // Buffer loads bounded at `size` rows: a row past the position is out of range and comes back as zeros WITHOUT a memory
+    // request and without a branch (as `if (t < size) load` this compiled to eight exec-masked blocks with an s_waitcnt vmcnt(0)
+    // in the middle of them and another one in front of the first dot product: three dependent round trips, ~2 us).
+    // (sched_barrier: request order = arrival order -- q, every K row, every V row; the scores, the two softmax barriers and the
+    // exponentials run while the V rows are still landing. Left alone, hipcc requested q last.)
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned row_bytes = (unsigned)kv_dim * 2u;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.key_cache, 0, (unsigned)size * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.value_cache, 0, (unsigned)size * row_bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)hoff * 2u;
     u32x4 kv0[U], vv0[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int t = wave * R + row + u * stride;
-        kv0[u] = (u32x4){0u, 0u, 0u, 0u};
-        vv0[u] = (u32x4){0u, 0u, 0u, 0u};
-        if (t < ready) {
-            kv0[u] = *reinterpret_cast<const u32x4*>(kh + (size_t)t * kv_dim);
-            vv0[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)t * kv_dim);
-        }
-    }
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
+    for (int u = 0; u < U; u++)
+        kv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
     float wmax = -INFINITY;
@@ -108,10 +123,10 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
         }
     }
     wmax = wave_max(wmax);
-    if (!FUSED && a.dbg) ts[2] = __builtin_readcyclecounter();
+    if (STAMPS && a.dbg) ts[2] = __builtin_readcyclecounter();
     if (lane == 0) red_max[wave] = wmax;
     __syncthreads();                                                              // barrier 1: scores + wave maxima
-    if (!FUSED && a.dbg) ts[3] = __builtin_readcyclecounter();
+    if (STAMPS && a.dbg) ts[3] = __builtin_readcyclecounter();
 
     // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
     const float m = row16_max(red_max[lane & 15]);
@@ -124,7 +139,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     sum = wave_sum(sum);
     if (lane == 0) red_sum[wave] = sum;
     __syncthreads();                                                              // barrier 2: exps + wave sums
-    if (!FUSED && a.dbg) ts[4] = __builtin_readcyclecounter();
+    if (STAMPS && a.dbg) ts[4] = __builtin_readcyclecounter();
     // fixed order: DPP tree over the 16 wave sums
     sum = row16_sum(red_sum[lane & 15]);
     const float inv_sum = 1.0f / sum;       // one IEEE division; p = e * inv_sum is within 1 fp32 ulp of e / sum (:400)
@@ -180,7 +195,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
             for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
         }
     }
-    if (!FUSED && a.dbg) ts[5] = __builtin_readcyclecounter();
+    if (STAMPS && a.dbg) ts[5] = __builtin_readcyclecounter();
     __syncthreads();                                                              // barrier 3: output partials
     if (PUB) {
         // one granule (two outputs) per thread of wave 0, ONE store instruction per head, validated by its tag on the
@@ -204,6 +219,12 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
 #endif
             store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, as_u(hh), ho.tag);
             *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + tid * 2) = as_u(hh);
+        }
+        if (STAMPS && a.dbg && lane == 0) {
+            ts[6] = __builtin_readcyclecounter();
+            unsigned long long* d = a.dbg + ((size_t)h * NW + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = ts[i];
         }
     } else {
         for (int n = tid; n < head_size; n += NW * 64) {
@@ -329,7 +350,7 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = tid >> 6;
     const int row = lane / LPR, sub = lane % LPR;
-    const int size = *pPos + 1;
+    const int size = __builtin_amdgcn_readfirstlane(*pPos) + 1;
     const int t_base = sp * ATT_CHUNK;
     const int rec = head_size + ATT_REC_PAD;
     float* my = partials + ((size_t)h * nsp + sp) * rec;
@@ -340,15 +361,24 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
         const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
         // non-temporal: at these contexts the KV cache (>= 0.5 GB per token) does not stay in the 256 MB Infinity Cache;
         // the one-block kernel for short contexts keeps the default policy (its 128 MB per token does: 4.1 vs 4.6 us)
+        // request order = arrival order: q, every K row, every V row (see attention_body)
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 kv[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int t = t_base + wave * R + row + u * stride;
             const int tc = t < size ? t : size - 1;
             kv[u] = ld_nt(reinterpret_cast<const u32x4*>(kh + (size_t)tc * kv_dim));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t_base + wave * R + row + u * stride;
+            const int tc = t < size ? t : size - 1;
             vv[u] = ld_nt(reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim));
         }
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
+        __builtin_amdgcn_sched_barrier(0);
         float sc[U];
         float wmax = -INFINITY;
 #pragma unroll

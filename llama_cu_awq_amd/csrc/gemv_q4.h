@@ -83,13 +83,14 @@ struct GemvArgs {
 constexpr int ROLE_NONE = 0, ROLE_CONSUMER = 2;
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 struct Handoff {
-    unsigned tag;          // this launch's tag (epoch + 1; zeroed buffers never match)
+    unsigned tag;          // this launch's tag = the epoch word as the preceding launch left it (>= 1: zeroed buffers never match)
     u32x2v* pub;           // producer (attention role): granule vector to publish into ([dim/2])
     const u32x2v* sub;     // consumer: granule vector to read (o-proj: the attention output, [K/2])
     int sentinel;          // consumer: granule polled first (staggered over the blocks: few pollers per line)
     unsigned* error;       // set to 1 when a bounded poll ran out (results are garbage then; the host reports it)
-    bool dead;             // the error word was already set at entry (an earlier launch timed out and the host has not cleared the
-                           // state yet): results are void anyway, so nobody spins again -- a long queue of launches behind a failure drains at once
+    unsigned dead;         // the error word as read at entry, kept raw (arithmetic on it at entry would pull the load's wait there).
+                           // != 0: an earlier launch timed out and the host has not cleared the state yet -- results are void anyway,
+                           // so nobody spins again: a long queue of launches behind a failure drains at once
     bool mute;             // profiling build: this attention block does not publish (provokes a real time-out, tests/prof_cases.py)
     unsigned long long* stamp;   // profiling build: wall clock right after the wait
 };
@@ -257,7 +258,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
                 const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
                 xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
                 if (g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag) break;
-                if (tries >= POLL_LIMIT / 4 || ho.dead) { ok = false; break; }
+                if (tries >= POLL_LIMIT / 4 || ho.dead != 0u) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -377,14 +378,14 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     }
     if (ROLE == ROLE_CONSUMER) {   // every weight load is in flight (PRE == SLOTS): now wait for the producers' granules
         static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
-        if (tid == 0 && !ho.dead) {   // one lane polls ONE granule (spread over lines: few pollers per line) ...
+        if (tid == 0 && ho.dead == 0u) {   // one lane polls ONE granule (spread over lines: few pollers per line) ...
             unsigned i = 0;
             while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
             if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         // ... then the block reads the whole vector; every granule validates itself
-        if (!load_x_granules() && !ho.dead) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!load_x_granules() && ho.dead == 0u) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef Q4_PROFILING
         if (ho.stamp && tid == 0) *ho.stamp = wall_clock64();
 #endif

@@ -13,7 +13,7 @@
 //  * forward progress: consumers wait only for producers, producers wait for nobody, and the launcher admits the form only
 //    when the consumers alone cannot fill the stream's CUs (occupancy x CUs > o-proj blocks, attention_oproj_form): a slot
 //    is then always open to a producer; no dispatch order is assumed. Otherwise the layer runs the stand-alone launches.
-//  * the tag is the value of the model's epoch word at entry + 1. The word is advanced by the PRECEDING launch of the stream
+//  * the tag is the value of the model's epoch word at entry. The word is advanced by the PRECEDING launch of the stream
 //    (the fused QKV GEMV, gemv_q4.h `bump`), never by this one: all blocks read the same value, whatever their timing.
 //  * every wait is a bounded poll; one that runs out sets the model's sticky error word, which the token loops turn into a
 //    clean retry at fusion level 1 (q4_runtime.hip).
@@ -48,10 +48,15 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
     const unsigned b = blockIdx.x;
     Handoff ho = {};
     ho.error = a.sync + SYNC_ERROR;
-    // one 8-byte load: [0] the error word, [1] the epoch
-    const unsigned long long ee = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.sync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ho.tag = (unsigned)(ee >> 32) + 1u;
-    ho.dead = (unsigned)ee != 0u;
+    // one 8-byte sc1 load: [0] the error word, [1] the epoch. Through a lane-held (opaque) offset on purpose: for a load the
+    // compiler can prove wave-uniform it puts s_waitcnt vmcnt(0) + v_readfirstlane right here, and every block of the launch then
+    // starts with a second dependent memory round trip (kernel arguments -> this word) before it requests anything else
+    // (seen in the ISA; ~0.5 us of the launch). Like this the wait sits at the first use: the polls, or the publishing store.
+    unsigned zero_off = 0;
+    asm volatile("" : "+v"(zero_off));
+    const u32x2v ee = load_granule(reinterpret_cast<const u32x2v*>(a.sync), zero_off);
+    ho.tag = ee[1];          // (the fused QKV launch in front has advanced it: >= 1)
+    ho.dead = ee[0];
 #ifdef Q4_PROFILING
     ho.mute = a.mute != 0;
 #endif

@@ -114,6 +114,7 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.natt = n_heads * s.nsp;
     a.no = dim / (LA_WAVES * 4);
 #ifdef Q4_PROFILING
+    a.att.dbg = g_dbg ? g_dbg + 4096 * 4 : nullptr;      // per-wave cycle stamps of the attention role, behind the per-block records
     a.dbg = g_dbg;
     if (g_ao_mute > 0) { a.mute = 1; g_ao_mute--; }
 #endif

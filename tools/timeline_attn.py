@@ -1,29 +1,44 @@
 #!/usr/bin/env python3
-"""Per-wave s_memtime timeline of the attention kernel at a given context (profiling stamps via q4_set_debug_buffer)."""
-import ctypes as C, os, sys
+"""Per-wave cycle stamps (s_memtime) of the attention role inside the attention -> o-proj launch at a given context, next to
+the per-block wall-clock records of tools/timeline_block.py. Profiling build. tools/timeline_attn.py [context] [model]"""
+import ctypes as C
+import os
+import sys
+
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llama_cu_awq_amd import api, synth
-api.use_profiling_build()   # the measurement knobs live in libllama2_q4_prof.so only
-path = "/tmp/llama2_q4_synth_7b_seed20240229.bin"
+from llama_cu_awq_amd import api, synth   # noqa: E402
+
+api.use_profiling_build()
+ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+model = sys.argv[2] if len(sys.argv) > 2 else "7b"
+path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
-    synth.write_model(path, "7b")
-L = api.lib(); api.check(L.q4_set_device(0))
-s = C.c_void_p(); api.check(L.q4_stream_create(C.byref(s))); L.q4_set_stream(s)
+    synth.write_model(path, model)
+L = api.lib()
+api.check(L.q4_set_device(0))
+s = C.c_void_p()
+api.check(L.q4_stream_create(C.byref(s)))
+L.q4_set_stream(s)
 tr = api.Transformer(path)
-ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], ctx)      # fill the cache, pos = ctx
-api.synchronize()
-print("pos", tr.pos())
-dbg = api.DevBuf(nbytes=32 * 16 * 8 * 8 + 4096)
+tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], ctx)
 L.q4_set_use_graphs(0)
-print("attention graph-mode us/launch:", tr.bench_kernel_graph(6, 32, 20))
-tr.bench_kernel(6, 40)
-api.synchronize()
-L.q4_set_debug_buffer(None)
-t = dbg.get(np.uint64)[: 32 * 16 * 8].reshape(32 * 16, 8).astype(np.int64)
-names = ["entry", "pos loaded", "scores done (K,V,q arrived)", "barrier 1", "barrier 2 (exp,sum)", "PV + shuffles done", "end"]
-for a, b in [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (0, 6)]:
-    d = t[:, b] - t[:, a]
-    print("%-30s -> %-30s median %6d  p90 %6d  max %6d cycles" % (names[a], names[b], np.median(d), np.percentile(d, 90), d.max()))
+heads, nw = tr.config.n_heads, 8
+dbg = api.DevBuf(nbytes=4096 * 4 * 8 + heads * nw * 8 * 8)
+names = ["entry", "position loaded", "scores done (q, K arrived)", "barrier 1", "exp + sum, barrier 2", "P.V + row shuffles", "published"]
+for rep in range(3):
+    L.q4_set_debug_buffer(dbg.ptr)
+    tr.run_transformer(True)
+    api.synchronize()
+    L.q4_set_debug_buffer(None)
+    raw = dbg.get(np.uint64)
+    t = raw[4096 * 4: 4096 * 4 + heads * nw * 8].reshape(heads * nw, 8).astype(np.int64)
+    blk = raw[: 4096 * 4].reshape(4096, 4).astype(np.int64)
+    blk = blk[blk[:, 0] > 0]
+    att = blk[(blk[:, 3] & 0xFF) == 1]
+    print("rep %d (position %d): attention blocks %.2f us (median entry -> end, wall clock)" % (rep, tr.pos() - 1, np.median(att[:, 2] - att[:, 0]) / 100.0))
+    for a, b in [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (0, 6)]:
+        d = t[:, b] - t[:, a]
+        print("   %-28s -> %-28s median %6d  p90 %6d  max %6d cycles" % (names[a], names[b], np.median(d), np.percentile(d, 90), d.max()))
 tr.close()
