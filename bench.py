@@ -181,12 +181,25 @@ def main():
             api.synchronize()
         pos_first = tr.pos()
         net_avg, net_min, net_max, net_n = tr.bench_in_network(8, 16)
-        # the figure the roofline is priced on is the one of the mode the product runs in: per-launch cost inside a
-        # hipGraph over the ring of the 32 layers' weights (kernel + its boundary; rocprofv3's average of the traced eager
-        # run, profiles/r03_kernel_stats_7b_256_eager.csv, agrees with it, the untraced HIP-event figure is ~7 % lower
-        # and stays in the record as hip_event_us)
         graph_us = tr.bench_kernel_graph(0, 32, 20)
-        dom = {"us": round(graph_us, 3), "GBps": round(kb[0][1] / graph_us / 1e3, 1)}
+        # The roofline is priced on the kernel's own duration. Two measurements exist: HIP events around every gate/up launch of
+        # 16 untraced eager decode steps (live, here), and rocprofv3's kernel trace of a whole eager -n 256 decode (committed:
+        # profiles/r03_kernel_stats_7b_256_eager.csv, ~6 % longer: every dispatch is intercepted and serialised under the
+        # tracer). The line takes the LARGER of the two, so it never claims more than the committed profile supports; the
+        # per-launch cost inside a hipGraph (kernel + boundary) is reported next to it.
+        rocprof_us, rocprof_src = None, None
+        for tag in ("r03", "r02"):
+            cpath = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s_%d_eager.csv" % (tag, args.model, ntok))
+            if os.path.exists(cpath):
+                import csv
+                for r in csv.DictReader(open(cpath)):
+                    if "gemv_q4_kernel<2," in r["kernel"]:
+                        rocprof_us, rocprof_src = float(r["avg_us"]), "profiles/" + os.path.basename(cpath)
+                        break
+            if rocprof_us is not None:
+                break
+        kernel_us = max(net_avg, rocprof_us) if rocprof_us else net_avg
+        dom = {"us": round(kernel_us, 3), "GBps": round(kb[0][1] / kernel_us / 1e3, 1)}
         in_network = {}
         per_kernel = {}
         kv_dim = cfg.dim * cfg.n_kv_heads // cfg.n_heads
@@ -207,7 +220,7 @@ def main():
                               "frac": round(nb_ / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_, "first_position": p0_}
         in_network[kb[0][0]] = round(net_avg, 3)
         per_kernel[kb[0][0]] = {"hip_event_us": round(net_avg, 3), "graph_us": round(graph_us, 3), "bytes": kb[0][1],
-                                "frac": round(kb[0][1] / graph_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
+                                "frac": round(kb[0][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
         traffic, traffic_src = None, None
         # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
         for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -221,12 +234,16 @@ def main():
         roofline = {"bound": "hbm", "kernel": kb[0][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"],
-                    "timing": "per launch inside a hipGraph (the mode the token loop runs in): 20 replays of a 32-launch "
-                              "graph over the ring of the layers' weights, kernel + boundary",
+                    "timing": "kernel duration = max(live HIP-event average, rocprofv3 average of the committed eager trace)",
                     "hip_event_us": round(net_avg, 3), "hip_event_min_us": round(net_min, 3), "hip_event_launches": net_n,
                     "hip_event_frac": round(kb[0][1] / net_avg / 1e3 / HBM_PEAK_GBS, 4),
                     "hip_event_timing": "HIP events (hipExtLaunchKernelGGL start/stop) on the launch stream, every gate/up "
                                         "launch of 16 eager decode steps from position 64 (untraced; excludes the boundary)",
+                    "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src,
+                    "graph_us_per_launch": round(graph_us, 3),
+                    "graph_frac": round(kb[0][1] / graph_us / 1e3 / HBM_PEAK_GBS, 4),
+                    "graph_timing": "per launch inside a hipGraph (the mode the token loop runs in): 20 replays of a 32-launch "
+                                    "graph over the ring of the layers' weights, kernel + boundary",
                     "isolated_ring_us": kernels[kb[0][0]]["us"],
                     "per_kernel": per_kernel}
         kernels["in_network_us"] = in_network

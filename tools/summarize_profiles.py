@@ -60,6 +60,7 @@ GEOM = {"7b": (4096, 11008, 32000, 32), "13b": (5120, 13824, 32000, 40)}
 def algorithmic(kernel, model, ntok):
     """algorithmic bytes per launch of a kernel of the decode network (weights + metadata + vectors in / out)"""
     d, h, v, _ = GEOM[model]
+    kernel = kernel[4:] if kernel.startswith("q4::") else kernel
     if kernel.startswith("gemv_q4_kernel<2"):
         return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
     if kernel.startswith("gemv_q4_kernel<1"):
@@ -70,10 +71,11 @@ def algorithmic(kernel, model, ntok):
         return v * d * 2 + d * 2 + v * 2
     if kernel.startswith("attention_oproj_kernel"):
         # o-proj QWeight + residual in / out + q + attention output + K and V rows of positions 0..pos, averaged over the
-        # positions this form serves in a -n ntok run (form = third template argument: 0 bin 128, 1 bin 256, 2 / 3 split bins)
+        # positions this form serves in an EAGER -n ntok run (form = third template argument; without graphs the network is
+        # launched with the exact context length instead of the bin: 0 up to 128, 1 up to 511, 2 up to 1023, 3 above)
         m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel)
         form = int(m.group(1)) if m else 0
-        lo, hi = {0: (0, 128), 1: (128, 256), 2: (256, 1024), 3: (1024, 2048)}[form]
+        lo, hi = {0: (0, 128), 1: (128, 512), 2: (512, 1024), 3: (1024, 2048)}[form]
         hi = min(hi, ntok)
         avg_rows = (lo + hi + 1) / 2.0
         return int(qweight_bytes(d, d) + 4 * d * 2 + avg_rows * 2 * d * 2)
@@ -106,7 +108,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
     print(model, ntok, json.dumps(per)[:600])
 if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
     for k, e in traffic["7b_n256"].items():
-        if k.startswith("gemv_q4_kernel<2"):
+        if k.replace("q4::", "").startswith("gemv_q4_kernel<2"):
             traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
 traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
