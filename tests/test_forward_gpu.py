@@ -291,3 +291,31 @@ def test_gpu_is_as_close_to_unrounded_arithmetic_as_the_restatement(q4, orc, mod
         assert eg <= 2.0 * er + 1e-3, (pos, eg, er)
     t.close()
     m.close()
+
+
+def test_sampler_rng_after_an_early_stop_matches_one_draw_per_executed_step(q4, models):
+    """sample() draws one coin per run_transformer call (sampler.h:45), also on greedy steps. The token loops queue steps eight
+    at a time; when EOS ends the generation inside such a group (the loop looks at tokens[pos], llama2_q4.cu:473-477 -- a prompt
+    that contains token 2 stops there) the surplus steps' draws are taken back, so a Sampler that is used again continues
+    exactly like the reference's: pos + 1 draws after a stop at position pos."""
+    import ctypes as C
+
+    class SamplerStruct(C.Structure):
+        _fields_ = [("vocab_size", C.c_int), ("indices", C.c_void_p), ("tempStorage_scan", C.c_void_p), ("tempStorage_sort", C.c_void_p),
+                    ("temp_storage_bytes_scan", C.c_size_t), ("temp_storage_bytes_sort", C.c_size_t), ("temperature", C.c_float),
+                    ("topp", C.c_float), ("rng_state", C.c_ulonglong)]
+
+    L = q4.lib()
+    seed = 1234
+    for stop in (5, 1, 7, 10):                                       # inside the first group, at its edge, inside the second
+        prompt = [1] + [5 + i for i in range(15)]
+        prompt[stop] = 2
+        t = q4.Transformer(models["tiny"], seed=seed)
+        toks, tps, timed, secs = t.generate_ids(prompt, 40)
+        assert timed + 1 == stop                                     # pos at the break (timed_tokens = pos - 1, :488)
+        state = C.c_ulonglong(seed)
+        for _ in range(stop + 1):
+            L.random_u32(C.byref(state))
+        got = C.cast(t.sampler, C.POINTER(SamplerStruct)).contents.rng_state
+        assert got == state.value, (stop, got, state.value)
+        t.close()
