@@ -16,6 +16,7 @@ dbg = api.DevBuf(nbytes=nw * 8 * 8 + 4096)
 L.q4_set_gemv_tune(3, 2, 4)
 L.q4_set_gemv_early(3, int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 L.q4_set_ablate(3)
+L.q4_set_debug_buffer(dbg.ptr)
 tr.bench_kernel(0, 40)          # several launches, buffer keeps the last one
 api.synchronize()
 t = dbg.get(np.uint64)[: nw * 8].reshape(nw, 8).astype(np.int64)
