@@ -38,8 +38,11 @@ struct AttArgs {
 // U: wave instructions in flight per pass, NW: waves per block (U * NW * R positions per pass)
 // FUSED: 0 stand-alone; 2 attention role of the attention -> o-proj launch (inputs from the previous launch, output published as
 // data-tagged granules for the o-proj blocks of the same launch)
-template <int LPR, int U, int NW, int FUSED>
+// PAD: head_size is not LPR * 8 (any multiple of 8 up to 256, like the reference's kernels: heads of 80, 96, 160 ...): the lanes
+// past the head's last 16-byte slice address slice 0 and multiply by a zero q
+template <int LPR, int U, int NW, int FUSED, bool PAD = false>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
+    static_assert(!PAD || !FUSED, "padded heads: stand-alone kernel only");
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr bool PUB = FUSED != 0;
 #ifdef Q4_PROFILING
@@ -60,25 +63,26 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     const int row = lane / LPR, sub = lane % LPR;            // position within the instruction, 16-B slice of the row
     constexpr int stride = NW * R;                           // positions per block step
     constexpr int group = stride * U;                        // positions per block pass
-    const size_t hoff = (size_t)(h / a.kv_mul) * head_size + sub * 8;   // this lane's 16-B slice inside a cache row
+    const bool lane_on = !PAD || sub * 8 < head_size;
+    const int subc = lane_on ? sub : 0;
+    const size_t hoff = (size_t)(h / a.kv_mul) * head_size + subc * 8;   // this lane's 16-B slice inside a cache row
     const q4_half* kh = a.key_cache + hoff;
     const q4_half* vh = a.value_cache + hoff;
     if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
     const int size = __builtin_amdgcn_readfirstlane(*a.pPos) + 1;     // wave-uniform by construction: descriptors below stay in SGPRs
     if (STAMPS && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
-    // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at
-    // context <= `group` positions (rows past the position are not requested at all: requesting the whole bin ahead of the
-    // position word, to save that dependent latency, was measured 22-31 us per token SLOWER at 7B -- the bytes cost more)
-    // Request order = arrival order (a wave's loads return in order): q first, then every K row, then every V row. One head is
-    // one CU pulling (position + 1) x 512 B at ~26 GB/s (measured: 1.95 us at position 100, 3.2 us at 200, s_memtime stamps of
-    // tools/timeline_attn.py); the scores, the two softmax barriers and the exponentials run while the V rows are still landing.
-    // Buffer loads bounded at `size` rows: a row past the position is out of range and comes back as zeros WITHOUT a memory
-    // request and without a branch (as `if (t < size) load` this compiled to eight exec-masked blocks with an s_waitcnt vmcnt(0)
-    // in the middle of them and another one in front of the first dot product: three dependent round trips, ~2 us).
-    // (sched_barrier: request order = arrival order -- q, every K row, every V row; the scores, the two softmax barriers and the
-    // exponentials run while the V rows are still landing. Left alone, hipcc requested q last.)
-    const u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + sub * 8);
+    // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at context <= `group`
+    // positions. Request order = arrival order (a wave's loads return in order), pinned with sched_barriers: q, every K row,
+    // every V row -- the scores, the two softmax barriers and the exponentials run while the V rows are still landing (left
+    // alone, hipcc requested q last). Buffer loads bounded at `size` rows: a row past the position is out of range and comes
+    // back as zeros WITHOUT a memory request and without a branch; as `if (t < size) load` this compiled to eight exec-masked
+    // blocks with an s_waitcnt vmcnt(0) in the middle of them and another one in front of the first dot product: three
+    // dependent round trips, ~2 us (s_memtime stamps, tools/timeline_attn.py). Rows past the position are not requested at all:
+    // requesting the whole bin ahead of the position word, to save that dependent latency, was measured 22-31 us per token
+    // SLOWER at 7B -- the bytes cost more.
+    u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + subc * 8);
+    if (PAD && !lane_on) qv = (u32x4){0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
     const unsigned row_bytes = (unsigned)kv_dim * 2u;
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.key_cache, 0, (unsigned)size * row_bytes, 0x00020000);
@@ -175,7 +179,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
     // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
     // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
-    if constexpr (LPR == 16) {
+    if constexpr (LPR == 16 && !PAD) {
         const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
         const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
         outp[wave * head_size + sub * 8 + row] = s0;
@@ -190,7 +194,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
             if (LPR <= 4) v += __shfl_xor(v, 4);
             acc[e] = v;
         }
-        if (lane < LPR) {
+        if (lane < LPR && lane_on) {
 #pragma unroll
             for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
         }
@@ -245,9 +249,9 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     }
 }
 
-template <int LPR, int U = 4, int NW = ATT_NW>
+template <int LPR, int U = 4, int NW = ATT_NW, bool PAD = false>
 __global__ void __launch_bounds__(NW * 64) attention_kernel(const AttArgs a) {
-    attention_body<LPR, U, NW, 0>(a, blockIdx.x, Handoff{});
+    attention_body<LPR, U, NW, 0, PAD>(a, blockIdx.x, Handoff{});
 }
 
 // Long contexts: the same block, but one per (head, 256-position chunk) so that all CUs pull on the KV cache (at

@@ -406,7 +406,22 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
             } else Q4_ATT(16)
             break;
         case 256: Q4_ATT(32) break;
-        default: return Q4_ERR_UNSUPPORTED_SIZE;
+        default: {
+            // any other multiple of 8 up to 256 (the reference's kernels take any head size): the next wider instantiation with the
+            // lanes past the head masked
+            if (head_size < 8 || head_size > 256 || (head_size & 7)) return Q4_ERR_UNSUPPORTED_SIZE;
+#define Q4_ATT_PAD(L)                                                                                                       \
+    {                                                                                                                       \
+        static size_t opted = 64 * 1024;                                                                                    \
+        if (smem > opted) {                                                                                                 \
+            Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L, 4, ATT_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+            opted = smem;                                                                                                   \
+        }                                                                                                                   \
+        Q4_LAUNCH((attention_kernel<L, 4, ATT_NW, true>), grid, block, smem, aa);                                           \
+    }
+            if (head_size < 32) Q4_ATT_PAD(4) else if (head_size < 64) Q4_ATT_PAD(8) else if (head_size < 128) Q4_ATT_PAD(16) else Q4_ATT_PAD(32)
+#undef Q4_ATT_PAD
+        }
     }
 #undef Q4_ATT
     Q4_LAUNCH_CHECK();

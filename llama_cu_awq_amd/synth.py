@@ -48,6 +48,8 @@ GEOMETRIES = {
     "tinyllama": (2048, 5632, 2, 32, 4, 512, 1100, 10000.0),
     "head256": (1024, 2816, 2, 4, 2, 512, 600, 10000.0),
     "head128_k8192": (8192, 1408, 1, 64, 8, 512, 300, 1000000.0),
+    "head96": (768, 2048, 2, 8, 8, 512, 300, 10000.0),           # a head size that is no power of two (stand-alone attention, lanes masked)
+    "head80_gqa": (640, 1728, 2, 8, 2, 512, 300, 10000.0),
     # the sampler at production vocabulary sizes on a one-layer body: 32000 = the register/LDS path with 32 keys per
     # thread, 40000 = the global-memory fallback (> 32 x 1024 entries)
     "v32k": (64, 96, 1, 2, 2, 32000, 32, 10000.0),

@@ -16,7 +16,7 @@ def models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     out = {}
     for name in ("tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head64_long", "head128_gqa", "tinyllama", "head256",
-                 "head128_k8192"):
+                 "head128_k8192", "head96", "head80_gqa"):
         p = str(d / (name + ".bin"))
         synth.write_model(p, name, seed=7)
         out[name] = p
@@ -26,7 +26,7 @@ def models(tmp_path_factory):
 # measured worst case per model (tools/measure_tolerances.py, profiles/r02_parity_observed.json): one fp16 ulp of an O(1)
 # logit = 9.8e-4 (longk_gqa, logits up to 2.2: 1.7e-3); the bounds are 3x that
 BOUND = {"tiny": 3e-3, "tiny_gqa": 3e-3, "small": 3e-3, "longk_gqa": 5e-3, "head128": 5e-3, "head128_k5120": 5e-3, "head128_gqa": 5e-3,
-         "tinyllama": 5e-3, "head256": 5e-3, "head128_k8192": 1.5e-2}   # K = 8192: measured 5.0e-3 (5 fp16 ulps of a logit below 1)
+         "tinyllama": 5e-3, "head256": 5e-3, "head128_k8192": 1.5e-2, "head96": 3e-3, "head80_gqa": 3e-3}   # K = 8192: measured 5.0e-3 (5 fp16 ulps of a logit below 1)
 
 
 def _logit_close(gpu, ref, bound=5e-3):
@@ -35,7 +35,7 @@ def _logit_close(gpu, ref, bound=5e-3):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head128_gqa", "tinyllama", "head256",
-                                  "head128_k8192"])
+                                  "head128_k8192", "head96", "head80_gqa"])
 @pytest.mark.parametrize("fusion,graphs", [(3, 1), (1, 1), (0, 1), (3, 0), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()

@@ -69,7 +69,10 @@ def _attention_close(got, ref, frac_gt1=0.03):
 @pytest.mark.parametrize("heads,kv_mul,hs,pos,seq", [(32, 1, 128, 0, 128), (32, 1, 128, 255, 256), (32, 1, 128, 300, 512),
                                                       (8, 4, 64, 40, 128), (4, 1, 64, 63, 64), (4, 2, 256, 9, 128),
                                                       (8, 1, 32, 20, 128), (32, 1, 128, 2047, 2048),
-                                                      (32, 1, 128, 127, 128), (8, 2, 128, 77, 128), (32, 1, 128, 128, 256)])
+                                                      (32, 1, 128, 127, 128), (8, 2, 128, 77, 128), (32, 1, 128, 128, 256),
+                                                      # head sizes that are no power of two (the reference's kernels take any: :267-284)
+                                                      (8, 1, 96, 50, 128), (8, 2, 80, 300, 512), (4, 1, 160, 700, 1024), (6, 3, 24, 17, 64),
+                                                      (4, 1, 200, 1500, 2048)])
 def test_attention(q4, orc, rng, heads, kv_mul, hs, pos, seq):
     dim = heads * hs
     kv_dim = dim // kv_mul
