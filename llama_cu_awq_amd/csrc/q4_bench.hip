@@ -21,7 +21,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
         case 5: return q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f);
         case 6: return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
                                         p->n_heads / p->n_kv_heads, p->seq_len, s->pos, (float*)s->att,
-                                        (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half), nullptr);
+                                        att_buffer_bytes(p), nullptr);
         case 7: return q4_rmsnorm(s->xb, s->x, w->rms_final_weight, dim);
         case 8: return q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 0);
         case 9: return q4_copy_embedding(s->x, w->token_embedding_table, dim, s->shared_data->tokens, s->pos);

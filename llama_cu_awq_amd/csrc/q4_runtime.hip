@@ -326,7 +326,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         s->xb = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
         s->hb = (q4_half*)c.take((size_t)p->hidden_dim * sizeof(q4_half));
         s->q = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
-        s->att = (q4_half*)c.take((size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half));
+        s->att = (q4_half*)c.take(att_buffer_bytes(p));
         s->logits = (q4_half*)c.take((size_t)p->vocab_size * sizeof(q4_half));
         s->key_cache = (q4_half*)c.take(sizeof(q4_half) * p->n_layers * p->seq_len * kv_dim);
         s->value_cache = (q4_half*)c.take(sizeof(q4_half) * p->n_layers * p->seq_len * kv_dim);
@@ -459,7 +459,7 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
 
     Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
-    const size_t att_bytes = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
+    const size_t att_bytes = att_buffer_bytes(p);
     // :320-323 as ONE launch where the geometry, the bin and the stream's CUs admit it (layer_attn.h); the launch in front of it
     // (the fused QKV GEMV) advances its epoch word
     const bool ao = g_fusion >= 3 && sync &&
