@@ -450,15 +450,91 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
             } else {
                 r4 = (f32x4){m, l, 0.f, 0.f};
             }
+            if (PUB) {       // the record leaves as data-tagged granules {float, tag}: whoever merges validates every word by itself
+                u32x2v* g = reinterpret_cast<u32x2v*>(partials) + ((size_t)h * nsp + sp) * rec + tid * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) store_granule(g + k, (unsigned)as_i(r4[k]), ho.tag);
+            } else {
             float* dst = my + tid * 4;
             if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
             else *reinterpret_cast<f32x4*>(dst) = r4;
+            }
+        }
+    } else if (PUB) {        // a chunk entirely in the future: the whole neutral record (m = -inf, l = 0, acc = 0), tagged
+        if ((int)tid < rec) {
+            u32x2v* g = reinterpret_cast<u32x2v*>(partials) + ((size_t)h * nsp + sp) * rec;
+            store_granule(g + tid, (unsigned)as_i((int)tid == head_size ? -INFINITY : 0.f), ho.tag);
         }
     } else if (tid == 0) {
         const f32x4 r4 = {-INFINITY, 0.f, 0.f, 0.f};
         float* dst = my + head_size;
         if (arrive) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r4) : "memory");
         else *reinterpret_cast<f32x4*>(dst) = r4;
+    }
+    if (PUB) {
+        // ---- merge by the head's FIRST chunk block (its chunk always holds position 0): the other chunks' records arrive as
+        // granules of this launch's tag, no drain, no arrival counter, no returning atomic on anybody's path (the last-arriver
+        // form below cost the merging block ~2.7 us after its own chunk: write-through drain, counter round trip, dependent loads).
+        // Same arithmetic and order as combine_partials.
+        if (sp != 0 || (int)tid >= head_size / 2) return;
+        const u32x2v* gh = reinterpret_cast<const u32x2v*>(partials) + (size_t)h * nsp * rec;
+        constexpr int B = 8;
+        float M = -INFINITY, denom = 0.f, num0 = 0.f, num1 = 0.f;
+        bool ok = true;
+        auto fetch = [&](int s0, float (&mv)[B], float (&lv)[B], float (&a0)[B], float (&a1)[B]) {
+            for (unsigned tries = 0;; tries++) {
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const unsigned kk = (unsigned)(s0 + k < nsp ? s0 + k : s0) * (unsigned)rec;
+                    const u32x4 ml = load_granule2(gh, kk + (unsigned)head_size);       // {m, tag, l, tag}
+                    const u32x4 aa = load_granule2(gh, kk + 2u * tid);                  // {acc[2 tid], tag, acc[2 tid + 1], tag}
+                    mv[k] = as_f((int)ml[0]); lv[k] = as_f((int)ml[2]); a0[k] = as_f((int)aa[0]); a1[k] = as_f((int)aa[2]);
+                    all = all && ml[1] == ho.tag && ml[3] == ho.tag && aa[1] == ho.tag && aa[3] == ho.tag;
+                }
+                if (all) return;
+                if (tries >= POLL_LIMIT / 4 || ho.dead != 0u) { ok = false; return; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        };
+        if (nsp <= B) {                       // one set of loads
+            float mv[B], lv[B], a0[B], a1[B];
+            fetch(0, mv, lv, a0, a1);
+#pragma unroll
+            for (int k = 0; k < B; k++) if (k < nsp) M = fmaxf(M, mv[k]);
+#pragma unroll
+            for (int k = 0; k < B; k++) if (k < nsp) denom += lv[k] * expf(mv[k] - M);
+#pragma unroll
+            for (int k = 0; k < B; k++)
+                if (k < nsp) { const float w = expf(mv[k] - M); num0 += w > 0.f ? a0[k] * w : 0.f; num1 += w > 0.f ? a1[k] * w : 0.f; }
+        } else {
+            for (int s0 = 0; s0 < nsp; s0 += B) {
+                float mv[B], lv[B], a0[B], a1[B];
+                fetch(s0, mv, lv, a0, a1);
+#pragma unroll
+                for (int k = 0; k < B; k++) if (s0 + k < nsp) M = fmaxf(M, mv[k]);
+            }
+            for (int s0 = 0; s0 < nsp; s0 += B) {
+                float mv[B], lv[B], a0[B], a1[B];
+                fetch(s0, mv, lv, a0, a1);
+#pragma unroll
+                for (int k = 0; k < B; k++)
+                    if (s0 + k < nsp) {
+                        const float w = expf(mv[k] - M);
+                        denom += lv[k] * w;
+                        num0 += w > 0.f ? a0[k] * w : 0.f;
+                        num1 += w > 0.f ? a1[k] * w : 0.f;
+                    }
+            }
+        }
+        if (!ok && ho.dead == 0u) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned data = (unsigned)f2h(num0 / denom) | ((unsigned)f2h(num1 / denom) << 16);
+        *reinterpret_cast<unsigned*>(output + (size_t)h * head_size + 2 * tid) = data;
+#ifdef Q4_PROFILING
+        if (!ho.mute)
+#endif
+        store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, data, ho.tag);
+        return;
     }
     if (arrive == nullptr) return;
     // ---- last-arriver merge: record drained to memory, then ONE returning arrival per block ------------------------
@@ -471,18 +547,7 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
     }
     __syncthreads();
     if (!is_last) return;
-    if (PUB) {   // two outputs per thread: one granule for this launch's o-proj blocks + the plain copy
-        if ((int)tid < head_size / 2) {
-            q4_half* oh = output + (size_t)h * head_size;
-            const unsigned lo = combine_partials<true>(oh, partials + (size_t)h * nsp * rec, head_size, nsp, 2 * tid);
-            const unsigned hi = combine_partials<true>(oh, partials + (size_t)h * nsp * rec, head_size, nsp, 2 * tid + 1);
-            const unsigned data = lo | (hi << 16);
-#ifdef Q4_PROFILING
-            if (!ho.mute)
-#endif
-            store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, data, ho.tag);
-        }
-    } else {
+    {
         for (int n = tid; n < head_size; n += NW * 64)
             combine_partials<true>(output + (size_t)h * head_size, partials + (size_t)h * nsp * rec, head_size, nsp, n);
     }

@@ -35,10 +35,13 @@ struct AttOprojArgs {
     int mute;                        // profiling build: the attention blocks do not publish (a real time-out for tests/prof_cases.py)
 };
 
-// ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3: one block per (head, 128 / 256
-// positions), merged by each head's last block. LPR = lanes per cache row of a head (head_size / 8).
+// ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3 / 4: one block per (head, 128 / 256 / 64
+// positions), merged by each head's first chunk block. LPR = lanes per cache row of a head (head_size / 8).
 template <int LPR, int ATT>
-struct AttShape { static constexpr int U = (ATT == 0 || ATT == 2 ? 128 : 256) / (LA_WAVES * (64 / LPR)); };
+struct AttShape {
+    static constexpr int CHUNK = ATT == 4 ? 64 : ATT == 0 || ATT == 2 ? 128 : 256;
+    static constexpr int U = CHUNK / (LA_WAVES * (64 / LPR));
+};
 
 template <int SLOTS, bool HALF, int ATT, int LPR>
 __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const AttOprojArgs a) {
@@ -101,19 +104,22 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             Q4_LAUNCH_CHECK();                                                                                            \
             return Q4_OK;                                                                                                 \
         };                                                                                                                \
-        switch (slots_kind * 4 + att) {                                                                                   \
+        switch (slots_kind * 8 + att) {                                                                                   \
             case 0: return go(attention_oproj_kernel<2, false, 0, LPR>);                                                  \
             case 1: return go(attention_oproj_kernel<2, false, 1, LPR>);                                                  \
             case 2: return go(attention_oproj_kernel<2, false, 2, LPR>);                                                  \
             case 3: return go(attention_oproj_kernel<2, false, 3, LPR>);                                                  \
-            case 4: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                   \
-            case 5: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                   \
-            case 6: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                   \
-            case 7: return go(attention_oproj_kernel<3, true, 3, LPR>);                                                   \
-            case 8: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                  \
-            case 9: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                  \
-            case 10: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
-            case 11: return go(attention_oproj_kernel<4, false, 3, LPR>);                                                 \
+            case 4: return go(attention_oproj_kernel<2, false, 4, LPR>);                                                  \
+            case 8: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                   \
+            case 9: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                   \
+            case 10: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                  \
+            case 11: return go(attention_oproj_kernel<3, true, 3, LPR>);                                                  \
+            case 12: return go(attention_oproj_kernel<3, true, 4, LPR>);                                                  \
+            case 16: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                 \
+            case 17: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                 \
+            case 18: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
+            case 19: return go(attention_oproj_kernel<4, false, 3, LPR>);                                                 \
+            case 20: return go(attention_oproj_kernel<4, false, 4, LPR>);                                                 \
         }                                                                                                                 \
         return Q4_ERR_UNSUPPORTED_SIZE;                                                                                   \
     }

@@ -52,11 +52,14 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     s.launch = head_size == 64 ? launch_attention_oproj_h64 : head_size == 128 ? launch_attention_oproj_h128 :
                head_size == 256 ? launch_attention_oproj_h256 : nullptr;
     if (!s.launch || !(kv_dim > 0 && dim % kv_dim == 0 && (dim % (LA_WAVES * 4)) == 0)) return s;
-    const int chunk = split_chunk ? split_chunk : (seq_len_bin <= 1024 ? 128 : 256);
+    // eight chunks per head = one attention block per CU at 32 heads (measured per bin, tools/sweep_attn_bins.py), 64..256 positions
+    const int auto_chunk = seq_len_bin <= 512 ? 64 : seq_len_bin <= 1024 ? 128 : 256;
+    const int chunk = split_chunk ? split_chunk : auto_chunk;
+    if (chunk != 64 && chunk != 128 && chunk != 256) return s;
     const int nsp = divUp(seq_len_bin, chunk);
     const bool split = seq_len_bin >= split_min && have_scratch && n_heads <= SYNC_MAX_HEADS &&
-                       (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(float) <= scratch_bytes;
-    if (split) { s.att = chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
+                       (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(u32x2v) <= scratch_bytes;   // records as {float, tag} granules
+    if (split) { s.att = chunk == 64 ? 4 : chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
     if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return s;
     s.att = seq_len_bin <= 128 ? 0 : 1;
     return s;
@@ -80,7 +83,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     // case; the split-context form of the last bin has more attention blocks than slots -- they queue behind each other.)
     const unsigned blocks = (unsigned)(n_heads * s.nsp + dim / (LA_WAVES * 4));
     static std::map<unsigned long long, int> occupancy;     // per instantiation and LDS size (the query is a host call)
-    const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 4 + s.att) << 32) | smem;
+    const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 8 + s.att) << 32) | smem;
     auto it = occupancy.find(key);
     if (it == occupancy.end()) {
         int n = 0;
@@ -88,7 +91,8 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
         it = occupancy.insert({key, n}).first;
     }
     const int per_cu = it->second;
-    const long long waiters = dim / (LA_WAVES * 4);
+    // (split-context forms: the head's first chunk block waits for the other chunks' records -- one more waiter per head)
+    const long long waiters = dim / (LA_WAVES * 4) + (s.att >= 2 ? n_heads : 0);
     if (g_ao_guard && (long long)per_cu * stream_cu_count() < waiters + 1) return -1;
     return s.att;
 }

@@ -43,7 +43,7 @@ static inline int divUp(int a, int b) { return (a - 1) / b + 1; }   // common.h:
 // (one record of head_size + 4 floats per head and chunk; this build keeps no scores there)
 static inline size_t att_buffer_bytes(const Config* p) {
     const size_t ref = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
-    const size_t rec = (size_t)p->n_heads * divUp(p->seq_len, 128) * (size_t)(p->dim / p->n_heads + 4) * sizeof(float);
+    const size_t rec = (size_t)p->n_heads * divUp(p->seq_len, 128) * (size_t)(p->dim / p->n_heads + 4) * 8;   // {float, tag} granules
     return ref > rec ? ref : rec;
 }
 
