@@ -72,10 +72,10 @@ def algorithmic(kernel, model, ntok):
     if kernel.startswith("attention_oproj_kernel"):
         # o-proj QWeight + residual in / out + q + attention output + K and V rows of positions 0..pos, averaged over the
         # positions this form serves in an EAGER -n ntok run (form = third template argument; without graphs the network is
-        # launched with the exact context length instead of the bin: 0 up to 128, 1 up to 511, 2 up to 1023, 3 above)
+        # launched with the exact context length instead of the bin: 0 up to 128, 1 up to 511, 4 at 512, 2 up to 1024, 3 above)
         m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel)
         form = int(m.group(1)) if m else 0
-        lo, hi = {0: (0, 128), 1: (128, 512), 2: (512, 1024), 3: (1024, 2048)}[form]
+        lo, hi = {0: (0, 128), 1: (128, 511), 2: (512, 1024), 3: (1024, 2048), 4: (511, 512)}.get(form, (0, ntok))
         hi = min(hi, ntok)
         avg_rows = (lo + hi + 1) / 2.0
         return int(qweight_bytes(d, d) + 4 * d * 2 + avg_rows * 2 * d * 2)
