@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock timeline (s_memrealtime, 10 ns) of the fused attention-block launch, per role: when the QKV blocks end,
 when the attention blocks pass their wait and end, when the o-proj blocks pass theirs and end. Profiling build.
-tools/timeline_block.py [model] [position]"""
+tools/timeline_block.py [model] [position] [fusion] [chunk min_bin]"""
 import ctypes as C
 import os
 import sys
@@ -24,6 +24,8 @@ s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 L.q4_set_fusion(fusion)
+if len(sys.argv) > 5:      # split-context setting: positions per block, smallest bin that splits
+    L.q4_set_attention_split(int(sys.argv[4]), int(sys.argv[5]))
 tr = api.Transformer(path)
 tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], upto)
 L.q4_set_use_graphs(0)
