@@ -219,6 +219,21 @@ def test_repeated_generations_are_identical_and_no_handoff_times_out(q4, m7b):
     t.close()
 
 
+def test_repeated_long_generations_through_the_split_context_bins(q4, m7b):
+    """The same soak through every sequence-length bin: 8 `-n 2048` generations (partial records of the split-context attention
+    cross CUs as data-tagged granules, merged by each head's first chunk block) must reproduce the first token ring."""
+    L = q4.lib()
+    before = L.q4_handoff_timeouts()
+    t = q4.Transformer(m7b)
+    ref = t.generate_ids(PROMPT, 2048)[0].copy()
+    for run in range(8):
+        toks = t.generate_ids(PROMPT, 2048)[0]
+        assert np.array_equal(toks, ref), "token ring changed in run %d" % run
+    q4.check(L.q4_handoff_status(t.state))
+    assert L.q4_handoff_timeouts() == before and L.q4_get_fusion() == q4.DEFAULT_FUSION
+    t.close()
+
+
 @pytest.mark.parametrize("n_cus", [32, 8])
 def test_masked_stream_falls_back_to_the_launch_sequence(q4, m7b, n_cus):
     """On a stream restricted to a few CUs the blocks of the attention -> o-proj launch are not all resident at once: the
