@@ -40,9 +40,18 @@ struct AttArgs {
 // data-tagged granules for the o-proj blocks of the same launch)
 // PAD: head_size is not LPR * 8 (any multiple of 8 up to 256, like the reference's kernels: heads of 80, 96, 160 ...): the lanes
 // past the head's last 16-byte slice address slice 0 and multiply by a zero q
-template <int LPR, int U, int NW, int FUSED, bool PAD = false>
-__device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho) {
+// VS > 1 (fused role only): VS = LPR / 4 blocks per head. Every one computes ALL scores of the head and the softmax (the K rows
+// of all but the first of them come out of the XCD's L2: the blocks of a head share an XCD), then takes ONE 64-byte slice of
+// the V rows -- 32 of the head's outputs -- with the whole wave: 4 lanes per row, 16 positions per wave instruction, so the
+// P.V pass costs 1/VS of the one-block form's instructions (with two waves per SIMD that pass is an issue-latency chain:
+// 1300-1950 of a head block's 6300-9600 cycles at positions 100 / 220, tools/timeline_attn.py), and publishes that slice. No
+// merge and no hand-off between the blocks of a head; the scores, the statistics and the rounding points are the one-block
+// form's, only the fp32 order in which an output sums its positions differs (16 positions per instruction instead of 4).
+template <int LPR, int U, int NW, int FUSED, bool PAD = false, int VS = 1>
+__device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho, const int vs = 0) {
     static_assert(!PAD || !FUSED, "padded heads: stand-alone kernel only");
+    static_assert(VS == 1 || (FUSED && LPR == 4 * VS && (U * (64 / LPR)) % 16 == 0), "V slices: fused role, 64-byte slices, whole wave instructions");
+    constexpr int UV = VS > 1 ? U * (64 / LPR) / 16 : U;   // V-slice form: wave instructions per pass (16 positions each)
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr bool PUB = FUSED != 0;
 #ifdef Q4_PROFILING
@@ -88,14 +97,21 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.key_cache, 0, (unsigned)size * row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.value_cache, 0, (unsigned)size * row_bytes, 0x00020000);
     const unsigned lane_off = (unsigned)hoff * 2u;
-    u32x4 kv0[U], vv0[U];
+    u32x4 kv0[U], vv0[UV];
 #pragma unroll
     for (int u = 0; u < U; u++)
         kv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (VS > 1) {      // lane = (position lane >> 2 of 16, 16-byte piece lane & 3 of the block's 64-byte slice)
+        const unsigned slice_off = ((unsigned)(h / a.kv_mul) * (unsigned)head_size + (unsigned)vs * 32u + (lane & 3u) * 8u) * 2u;
 #pragma unroll
-    for (int u = 0; u < U; u++)
-        vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
+        for (int u = 0; u < UV; u++)
+            vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * 16 + (int)(lane >> 2) + u * NW * 16) * row_bytes + slice_off, 0, 0);
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
@@ -152,51 +168,76 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
-    for (int g0 = 0; g0 < size; g0 += group) {
-        u32x4 vv[U];
+    if constexpr (VS > 1) {
+        // (the fused role never has more than one register-resident group: size <= the bin = `group`)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (g0 == 0) {
-                vv[u] = vv0[u];
-            } else {
-                const int t = g0 + wave * R + row + u * stride;
-                const int tc = t < size ? t : size - 1;
-                vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = g0 + wave * R + row + u * stride;
+        for (int u = 0; u < UV; u++) {
+            const int t = wave * 16 + (int)(lane >> 2) + u * NW * 16;
             const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const h2 v2 = as_h2(vv[u][e]);
+                const h2 v2 = as_h2(vv0[u][e]);
                 acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);          // :311
                 acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
             }
         }
-    }
-    // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
-    // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
-    // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
-    if constexpr (LPR == 16 && !PAD) {
-        const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
-        const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
-        outp[wave * head_size + sub * 8 + row] = s0;
-        outp[wave * head_size + sub * 8 + 4 + row] = s1;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float v = acc[e];
-            if (LPR <= 32) v += __shfl_xor(v, 32);
-            if (LPR <= 16) v += __shfl_xor(v, 16);
-            if (LPR <= 8) v += __shfl_xor(v, 8);
-            if (LPR <= 4) v += __shfl_xor(v, 4);
-            acc[e] = v;
+        // the four DPP rows with the transposing swaps (row r then holds elements r and 4 + r of the lane's 16-byte piece), then
+        // the four position lanes of a row that share a piece (lanes i, i + 4, i + 8, i + 12): two row rotations
+        float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));
+        float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));
+        s0 += dpp_mov<0x128>(s0); s0 += dpp_mov<0x124>(s0);                       // row_ror:8, row_ror:4
+        s1 += dpp_mov<0x128>(s1); s1 += dpp_mov<0x124>(s1);
+        if ((lane & 12u) == 0u) {
+            outp[wave * 32 + (lane & 3u) * 8 + (lane >> 4)] = s0;
+            outp[wave * 32 + (lane & 3u) * 8 + 4 + (lane >> 4)] = s1;
         }
-        if (lane < LPR && lane_on) {
+    } else {
+        for (int g0 = 0; g0 < size; g0 += group) {
+            u32x4 vv[U];
 #pragma unroll
-            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+            for (int u = 0; u < U; u++) {
+                if (g0 == 0) {
+                    vv[u] = vv0[u];
+                } else {
+                    const int t = g0 + wave * R + row + u * stride;
+                    const int tc = t < size ? t : size - 1;
+                    vv[u] = *reinterpret_cast<const u32x4*>(vh + (size_t)tc * kv_dim);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = g0 + wave * R + row + u * stride;
+                const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const h2 v2 = as_h2(vv[u][e]);
+                    acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);          // :311
+                    acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
+                }
+            }
+        }
+        // combine the R rows of a wave, then the waves through LDS. LPR == 16 (head 128): the four DPP rows are summed
+        // with the transposing permlane swaps of gemv_q4.h (VALU only): afterwards row r holds the 4-row totals of
+        // elements r and 4 + r of its 16-B slice -- instead of 16 ds_bpermute shuffles per lane
+        if constexpr (LPR == 16 && !PAD) {
+            const float s0 = swap16_add(swap32_add(acc[0], acc[2]), swap32_add(acc[1], acc[3]));   // rows: e0, e1, e2, e3
+            const float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));   // rows: e4, e5, e6, e7
+            outp[wave * head_size + sub * 8 + row] = s0;
+            outp[wave * head_size + sub * 8 + 4 + row] = s1;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float v = acc[e];
+                if (LPR <= 32) v += __shfl_xor(v, 32);
+                if (LPR <= 16) v += __shfl_xor(v, 16);
+                if (LPR <= 8) v += __shfl_xor(v, 8);
+                if (LPR <= 4) v += __shfl_xor(v, 4);
+                acc[e] = v;
+            }
+            if (lane < LPR && lane_on) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
+            }
         }
     }
     if (STAMPS && a.dbg) ts[5] = __builtin_readcyclecounter();
@@ -204,14 +245,15 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     if (PUB) {
         // one granule (two outputs) per thread of wave 0, ONE store instruction per head, validated by its tag on the
         // o-proj side; the plain copy keeps RunState::xb what the launch sequence leaves there
-        if ((int)tid < head_size / 2) {
+        if ((int)tid < head_size / (2 * VS)) {
+            const int g = vs * (head_size / (2 * VS)) + (int)tid;      // granule (pair of outputs) inside the head
             float s2[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const int n = tid * 2 + k;
+                const int n = g * 2 + k;
                 float part[NW];
 #pragma unroll
-                for (int w = 0; w < NW; w++) part[w] = outp[w * head_size + n];
+                for (int w = 0; w < NW; w++) part[w] = VS > 1 ? outp[w * 32 + (int)tid * 2 + k] : outp[w * head_size + n];
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; w++) s += part[w];
@@ -221,10 +263,10 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
 #ifdef Q4_PROFILING
             if (!ho.mute)
 #endif
-            store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, as_u(hh), ho.tag);
-            *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + tid * 2) = as_u(hh);
+            store_granule(ho.pub + (size_t)h * (head_size / 2) + g, as_u(hh), ho.tag);
+            *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + g * 2) = as_u(hh);
         }
-        if (STAMPS && a.dbg && lane == 0) {
+        if (STAMPS && a.dbg && lane == 0 && vs == 0) {
             ts[6] = __builtin_readcyclecounter();
             unsigned long long* d = a.dbg + ((size_t)h * NW + wave) * 8;
 #pragma unroll

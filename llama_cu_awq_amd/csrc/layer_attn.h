@@ -36,11 +36,13 @@ struct AttOprojArgs {
 };
 
 // ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3 / 4: one block per (head, 128 / 256 / 64
-// positions), merged by each head's first chunk block. LPR = lanes per cache row of a head (head_size / 8).
+// positions), merged by each head's first chunk block; 5 / 6: 0 / 1 with head_size / 32 blocks per head, each taking one 64-byte
+// slice of the V rows (attention.h, VS; the default below bin 512). LPR = lanes per cache row of a head (head_size / 8).
 template <int LPR, int ATT>
 struct AttShape {
-    static constexpr int CHUNK = ATT == 4 ? 64 : ATT == 0 || ATT == 2 ? 128 : 256;
+    static constexpr int CHUNK = ATT == 4 ? 64 : ATT == 0 || ATT == 2 || ATT == 5 ? 128 : 256;
     static constexpr int U = CHUNK / (LA_WAVES * (64 / LPR));
+    static constexpr int VS = ATT >= 5 ? LPR / 4 : 1;
 };
 
 template <int SLOTS, bool HALF, int ATT, int LPR>
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
     if (b < a.natt) {
         ho.pub = g_att;
         if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2>(a.att, (int)b, ho);
+        else if constexpr (ATT >= 5) attention_body<LPR, U, NW, 2, false, AttShape<LPR, ATT>::VS>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
         else attention_split_body<LPR, U, true, NW>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
     } else {
         const unsigned j = b - a.natt;
@@ -104,22 +107,28 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             Q4_LAUNCH_CHECK();                                                                                            \
             return Q4_OK;                                                                                                 \
         };                                                                                                                \
-        switch (slots_kind * 8 + att) {                                                                                   \
+        switch (slots_kind * 16 + att) {                                                                                  \
             case 0: return go(attention_oproj_kernel<2, false, 0, LPR>);                                                  \
             case 1: return go(attention_oproj_kernel<2, false, 1, LPR>);                                                  \
             case 2: return go(attention_oproj_kernel<2, false, 2, LPR>);                                                  \
             case 3: return go(attention_oproj_kernel<2, false, 3, LPR>);                                                  \
             case 4: return go(attention_oproj_kernel<2, false, 4, LPR>);                                                  \
-            case 8: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                   \
-            case 9: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                   \
-            case 10: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                  \
-            case 11: return go(attention_oproj_kernel<3, true, 3, LPR>);                                                  \
-            case 12: return go(attention_oproj_kernel<3, true, 4, LPR>);                                                  \
-            case 16: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                 \
-            case 17: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                 \
-            case 18: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
-            case 19: return go(attention_oproj_kernel<4, false, 3, LPR>);                                                 \
-            case 20: return go(attention_oproj_kernel<4, false, 4, LPR>);                                                 \
+            case 5: return go(attention_oproj_kernel<2, false, 5, LPR>);                                                  \
+            case 6: return go(attention_oproj_kernel<2, false, 6, LPR>);                                                  \
+            case 16: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                  \
+            case 17: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                  \
+            case 18: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                  \
+            case 19: return go(attention_oproj_kernel<3, true, 3, LPR>);                                                  \
+            case 20: return go(attention_oproj_kernel<3, true, 4, LPR>);                                                  \
+            case 21: return go(attention_oproj_kernel<3, true, 5, LPR>);                                                  \
+            case 22: return go(attention_oproj_kernel<3, true, 6, LPR>);                                                  \
+            case 32: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                 \
+            case 33: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                 \
+            case 34: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
+            case 35: return go(attention_oproj_kernel<4, false, 3, LPR>);                                                 \
+            case 36: return go(attention_oproj_kernel<4, false, 4, LPR>);                                                 \
+            case 37: return go(attention_oproj_kernel<4, false, 5, LPR>);                                                 \
+            case 38: return go(attention_oproj_kernel<4, false, 6, LPR>);                                                 \
         }                                                                                                                 \
         return Q4_ERR_UNSUPPORTED_SIZE;                                                                                   \
     }

@@ -12,6 +12,7 @@ int launch_attention_oproj_h128(int slots_kind, int att, dim3 grid, dim3 block, 
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
 
 int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention blocks of the next n launches do not publish
+int g_ao_vslice = 1;  // below the split-context bins: head_size / 32 attention blocks per head, one 64-byte V slice each (0: one block)
 int g_ao_guard = 1;   // profiling build: q4_set_gemv_early(8, 0) admits grids larger than the resident capacity (forward-progress tests)
 
 // CUs the launch stream may use: all of the device, or the bits of its CU mask (hipExtStreamCreateWithCUMask)
@@ -62,12 +63,13 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     if (split) { s.att = chunk == 64 ? 4 : chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
     if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return s;
     s.att = seq_len_bin <= 128 ? 0 : 1;
+    if (g_ao_vslice) { s.att += 5; s.nsp = head_size / 32; }
     return s;
 }
 
 static size_t ao_smem(const AoShape& s, int head_size, int seq_len_bin) {
     const size_t smem_gemv = (size_t)s.slots * 256 * 16 + (size_t)s.slots * 512 + (size_t)s.slots * 256 * 4 + 16;
-    const size_t smem_att = s.att >= 2 ? (size_t)(32 + LA_WAVES * head_size) * 4 : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem_att = s.att >= 2 && s.att <= 4 ? (size_t)(32 + LA_WAVES * head_size) * 4 : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
     return smem_gemv > smem_att ? smem_gemv : smem_att;
 }
 
@@ -83,7 +85,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     // case; the split-context form of the last bin has more attention blocks than slots -- they queue behind each other.)
     const unsigned blocks = (unsigned)(n_heads * s.nsp + dim / (LA_WAVES * 4));
     static std::map<unsigned long long, int> occupancy;     // per instantiation and LDS size (the query is a host call)
-    const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 8 + s.att) << 32) | smem;
+    const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 16 + s.att) << 32) | smem;
     auto it = occupancy.find(key);
     if (it == occupancy.end()) {
         int n = 0;
@@ -92,7 +94,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     }
     const int per_cu = it->second;
     // (split-context forms: the head's first chunk block waits for the other chunks' records -- one more waiter per head)
-    const long long waiters = dim / (LA_WAVES * 4) + (s.att >= 2 ? n_heads : 0);
+    const long long waiters = dim / (LA_WAVES * 4) + (s.att >= 2 && s.att <= 4 ? n_heads : 0);
     if (g_ao_guard && (long long)per_cu * stream_cu_count() < waiters + 1) return -1;
     return s.att;
 }

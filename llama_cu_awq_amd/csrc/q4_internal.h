@@ -95,6 +95,7 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
 extern int g_att_chunk;
 extern int g_att_split_min;
 extern int g_ao_guard;
+extern int g_ao_vslice;
 extern int g_multi_steps;
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,

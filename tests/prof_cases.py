@@ -94,8 +94,8 @@ def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, mod
     build): 160-400 blocks on 3 / 8 / 32 CUs, so most o-proj blocks are dispatched only after earlier blocks have left. The
     product never runs it that way (the guard falls back to the launch sequence, tests/test_baseline_configs_gpu.py); this
     case shows what the guard protects against does not bite on this hardware either: work-groups are dispatched in index
-    order, producers come first and wait for nobody. No bounded poll may run out; bits equal fusion level 1 in the first bin,
-    the model's bound above it (split-context bins included for the small model)."""
+    order, producers come first and wait for nobody. No bounded poll may run out; logits within the model's bound of fusion
+    level 1 (split-context bins included for the small model)."""
     import ctypes as C
     L = q4.lib()
     full = L.q4_get_stream()
@@ -129,13 +129,10 @@ def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, mod
         L.q4_set_fusion(q4.DEFAULT_FUSION)
     for a, b, pos in zip(outs[1][0], outs[3][0], cps):
         if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:
-            assert pos > 200, "token rings diverged early (%d)" % pos
+            assert pos > 60, "token rings diverged early (%d)" % pos
             break
-        if pos < 128:
-            assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), pos
-        else:
-            af, bf = a.astype(np.float64), b.astype(np.float64)
-            assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), pos
+        af, bf = a.astype(np.float64), b.astype(np.float64)      # (another fp32 grouping of the positions: the model's bound)
+        assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), pos
 
 
 def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_level_1(q4, tmp_path):
@@ -153,7 +150,7 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
         ptoks = np.concatenate([[1], np.arange(3, 23)]).astype(np.int32)
         want_ppl = t.perplexity_ids(ptoks)
         L.q4_set_fusion(q4.DEFAULT_FUSION)
-        assert np.array_equal(t.generate_ids(prompt, 40)[0], want)      # level 3, nothing sabotaged: same greedy ring (first bin)
+        assert np.array_equal(t.generate_ids(prompt, 40)[0][:12], want[:12])   # level 3, nothing sabotaged: same greedy tokens
         assert L.q4_handoff_timeouts() == 0
         L.q4_set_gemv_early(9, 1)                                       # the next attention -> o-proj launch is captured mute
         got = t.generate_ids(prompt, 40)[0]
@@ -168,3 +165,49 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
     finally:
         L.q4_set_gemv_early(9, 0)
         L.q4_set_fusion(q4.DEFAULT_FUSION)
+
+
+@pytest.mark.parametrize("model,steps", [("head128", 300), ("head128_k5120", 300), ("head128_gqa", 300), ("tinyllama", 300), ("head256", 300)])
+def test_one_block_and_v_slice_forms_of_the_attention_role(q4, model, steps):
+    """Attention role of the attention -> o-proj launch below the split-context bins. Knob 10 = 0: one block per head, the
+    stand-alone kernel's body -- for head 128 in the stand-alone kernel's shape, so in the first bin fusion level 3 must equal
+    level 1 BIT FOR BIT (any stale or torn granule of the hand-off would show). Knob 10 = 1, the default: head_size / 32 blocks
+    per head, every one computes all scores and the softmax and takes one 64-byte slice of the V rows, 16 positions per wave
+    instruction: same scores, same rounding points, another fp32 order over the positions -- the model's bound, equal greedy
+    tokens until a near-tie."""
+    L = q4.lib()
+    path = _model_file(model)
+    cps = (0, 3, 60, 127, 128, 200, 255, 256, steps - 1)
+    outs = {}
+    timeouts = L.q4_handoff_timeouts()      # (a counter of the process: an earlier case provokes a real one)
+    try:
+        for key, lvl, knob in (("level1", 1, 1), ("one_block", 3, 0), ("v_slices", 3, 1)):
+            L.q4_set_gemv_early(10, knob)
+            L.q4_set_fusion(lvl)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in cps:
+                    q4.synchronize()
+                    got.append(t.logits().view(np.uint16).copy())
+            q4.check(L.q4_handoff_status(t.state))
+            assert L.q4_handoff_timeouts() == timeouts and L.q4_get_fusion() == lvl
+            outs[key] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            t.close()
+    finally:
+        L.q4_set_gemv_early(10, 1)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
+    if model.startswith("head128"):
+        assert outs["one_block"][1][:128] == outs["level1"][1][:128]
+        for a, b, pos in zip(outs["level1"][0], outs["one_block"][0], cps):
+            if pos < 128:
+                assert np.array_equal(a, b), "one-block form differs from fusion level 1 at position %d" % pos
+    for other in ("one_block", "level1"):
+        for a, b, pos in zip(outs[other][0], outs["v_slices"][0], cps):
+            if outs[other][1][:pos + 1] != outs["v_slices"][1][:pos + 1]:
+                assert pos >= 60, "token rings diverged early (%d, V slices vs %s)" % (pos, other)
+                break
+            af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
+            assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), (pos, other)

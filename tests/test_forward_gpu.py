@@ -83,9 +83,9 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
 def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name, steps, checkpoints):
     """Fusion level 3 (attention -> o-proj as ONE launch, the hand-off inside the launch) against levels 1 and 0 across the
     sequence-length bins 128 / 256 (one block per head) and 512 / 1024 / seq_len (split context), for heads of 64 / 128 / 256,
-    multi-head and grouped-query, K = dim in one, two, three (shared half slot) and four k-slots: the arithmetic is the same
-    device code, so in the first bin the logits must be IDENTICAL, above it within the model's bound with equal greedy token
-    rings, and no bounded spin may have run out."""
+    multi-head and grouped-query, K = dim in one, two, three (shared half slot) and four k-slots: the same arithmetic with the
+    same rounding points, so the logits must agree within the model's bound with equal greedy token rings (until a near-tie),
+    levels 1 and 0 bit for bit, and no bounded spin may have run out."""
     L = q4.lib()
     outs = {}
     try:
@@ -106,25 +106,17 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
             t.close()
     finally:
         L.q4_set_fusion(q4.DEFAULT_FUSION)
-    # levels 1 and 3 run the same device code; in the first bin also in the same shapes: identical bits up to position 127
-    # (head 128; the stand-alone kernels of the other head sizes work with 16 waves there, the fused launch with 8).
-    # From bin 256 on the fused launch's attention role works with 8 waves x 8 rows in flight, the stand-alone kernel with
-    # 16 x 4 (faster on its own): another fp32 summation grouping, so from there on the comparison is the model's bound
-    same_shape_bin0 = name.startswith("head128")
-    for lvl in (3,):
-        ring_equal = True
-        for i, (a, b, pos) in enumerate(zip(outs[1][0], outs[lvl][0], checkpoints)):
-            if pos < 128 and same_shape_bin0:
-                assert np.array_equal(a, b), "logits differ at position %d (fusion 1 vs %d)" % (pos, lvl)
-            else:
-                ring_equal = ring_equal and outs[1][1][:pos + 1] == outs[lvl][1][:pos + 1]
-                if not ring_equal:     # a near-tie resolved the other way under another fp32 grouping: legitimate past the first bin
-                    assert pos >= (128 if same_shape_bin0 else 60), "token rings diverged early (%d, fusion %d)" % (pos, lvl)
-                    break
-                af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
-                assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), (pos, lvl)
-        if same_shape_bin0:
-            assert outs[1][1][:128] == outs[lvl][1][:128]
+    # levels 1 and 3 run the same device code with another fp32 grouping of an output's positions: below bin 512 the fused
+    # launch's attention role works with head_size / 32 blocks per head, 16 positions per wave instruction of a block's V slice
+    # (the stand-alone kernel: 4), and with 8 waves where the stand-alone kernel of the other head sizes has 16 -- so the
+    # comparison is the model's bound with equal greedy token rings. (The one-block form of the role, which reproduces level 1
+    # bit for bit in the first bin, is compared in tests/prof_cases.py.)
+    for a, b, pos in zip(outs[1][0], outs[3][0], checkpoints):
+        if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:    # a near-tie resolved the other way under another fp32 grouping
+            assert pos >= 60, "token rings diverged early (%d, fusion 3)" % pos
+            break
+        af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
+        assert (np.abs(af - bf) <= 5e-3 * np.maximum(1.0, np.abs(bf))).all(), pos
     # level 0 (the reference's 1:1 sequence): identical too, except where K = dim ends in a shared half slot (K = 5120):
     # there a column's half-slot terms sit in the lower or the upper 32 lanes depending on its place in the wave, and the
     # RoPE-paired column order of the fused QKV differs from the plain one -- same terms, another fp32 rounding sequence

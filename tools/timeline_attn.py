@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave cycle stamps (s_memtime) of the attention role inside the attention -> o-proj launch at a given context, next to
-the per-block wall-clock records of tools/timeline_block.py. Profiling build. tools/timeline_attn.py [context] [model]"""
+the per-block wall-clock records of tools/timeline_block.py. Profiling build.
+tools/timeline_attn.py [context] [model] [blocks per head: 0, 2 or 4 V slices]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +14,7 @@ from llama_cu_awq_amd import api, synth   # noqa: E402
 api.use_profiling_build()
 ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 model = sys.argv[2] if len(sys.argv) > 2 else "7b"
+vslice = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
 if not os.path.exists(path):
     synth.write_model(path, model)
@@ -21,6 +23,8 @@ api.check(L.q4_set_device(0))
 s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
+if vslice >= 0:
+    L.q4_set_gemv_early(10, vslice)
 tr = api.Transformer(path)
 tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], ctx)
 L.q4_set_use_graphs(0)
