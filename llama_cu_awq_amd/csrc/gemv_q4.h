@@ -179,7 +179,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     static_assert(!HALF || COLS % 2 == 0, "shared half slot: column pairs");
     constexpr int NMAT = ModeTraits<MODE>::NMAT;
     constexpr int NV = NMAT * COLS;             // column sums per wave
-    static_assert(NV == 4 || NV == 8, "row-distributed epilogue handles 4 or 8 sums per wave");
+    static_assert(NV == 4 || NV == 8 || (NV == 2 && MODE == MODE_PLAIN), "row-distributed epilogue handles 4 or 8 sums per wave (plain: 2 as well)");
     static_assert(KS == 1 || (KS == 2 && MODE == MODE_PLAIN && COLS == 4 && !NORM), "K split: plain GEMV, 4 columns");
     using Lds = LdsLayout<SLOTS, KS>;
     constexpr int TS = Lds::ROWS;               // 64-unit rows staged in LDS: the column's k-slots (+ the zero row of a K split)
@@ -479,6 +479,14 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
                 float r = tot;
                 if (a.accum) r += h2f(out[n]);                                      // :229-230
                 out[n] = f2h(r);                                                    // :231
+            }
+        } else if constexpr (COLS == 2) {   // rows 0 and 1 hold the two columns (the same pair sums as in the four-column form)
+            const float tot = reduce4_rows(colsum[0][0], colsum[0][1], 0.f, 0.f) * 1048576.f;
+            const int n = wg * 2 + row;
+            if (writer && row < 2 && n < N) {
+                float r = tot;
+                if (a.accum) r += h2f(out[n]);
+                out[n] = f2h(r);
             }
         } else {   // COLS == 8: row r holds columns 2r (w0) and 2r+1 (w1)
             const float w0 = reduce4_rows(colsum[0][0], colsum[0][2], colsum[0][4], colsum[0][6]) * 1048576.f;

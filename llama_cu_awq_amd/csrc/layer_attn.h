@@ -23,6 +23,11 @@
 
 namespace q4 {
 
+// Columns per wave of the o-proj role: dim / (8 * columns) blocks. K = dim in two k-slots (dim <= 4096): TWO -- 256 blocks of 16
+// columns at 7B, every CU of the device takes part in the dot products (with four columns per wave 128 CUs did them while the
+// CUs of the finished attention blocks idled): 7B -n 256 958.7 -> 972.2, -n 2048 858.6 -> 864.5 tokens/s (tools/ab.py, one call).
+// Longer K: four -- at 13B two columns per wave are 320 + 160 blocks, two per CU on most CUs: 534.4 -> 527.2.
+constexpr int la_ocols(int slots) { return slots <= 2 ? 2 : 4; }
 constexpr int LA_WAVES = 8;          // 512-thread blocks for both roles (16-wave o-proj blocks -- 64 of them -- lost 13-20 us per token)
 
 struct AttOprojArgs {
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
         const unsigned j = b - a.natt;
         ho.sub = g_att;
         ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);   // last granule of head j % heads
-        gemv_q4_body<MODE_PLAIN, SLOTS, 4, false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
+        gemv_q4_body<MODE_PLAIN, SLOTS, la_ocols(SLOTS), false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);
     }
 #ifdef Q4_PROFILING
     if (a.dbg && threadIdx.x == 0) a.dbg[b * 4 + 2] = wall_clock64();

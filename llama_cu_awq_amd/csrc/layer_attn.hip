@@ -52,7 +52,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     else return s;
     s.launch = head_size == 64 ? launch_attention_oproj_h64 : head_size == 128 ? launch_attention_oproj_h128 :
                head_size == 256 ? launch_attention_oproj_h256 : nullptr;
-    if (!s.launch || !(kv_dim > 0 && dim % kv_dim == 0 && (dim % (LA_WAVES * 4)) == 0)) return s;
+    if (!s.launch || !(kv_dim > 0 && dim % kv_dim == 0 && (dim % (LA_WAVES * la_ocols(s.slots))) == 0)) return s;
     // eight chunks per head = one attention block per CU at 32 heads (measured per bin, tools/sweep_attn_bins.py), 64..256 positions
     const int auto_chunk = seq_len_bin <= 512 ? 64 : seq_len_bin <= 1024 ? 128 : 256;
     const int chunk = split_chunk ? split_chunk : auto_chunk;
@@ -63,7 +63,9 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     if (split) { s.att = chunk == 64 ? 4 : chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
     if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return s;
     s.att = seq_len_bin <= 128 ? 0 : 1;
-    if (g_ao_vslice) { s.att += 5; s.nsp = head_size / 32; }
+    // (only where the bin is one register-resident group of the role, <= 256 positions: a model whose scratch does not hold
+    // the split form's records runs the one-block form, which walks longer contexts group by group, above that too)
+    if (g_ao_vslice && seq_len_bin <= 256) { s.att += 5; s.nsp = head_size / 32; }
     return s;
 }
 
@@ -83,7 +85,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     // dispatcher picks, the launch cannot wedge as long as the waiting blocks alone cannot fill the stream's CUs: a slot is then
     // always left for an attention block, and every attention block that runs ends. (All blocks resident at once is the common
     // case; the split-context form of the last bin has more attention blocks than slots -- they queue behind each other.)
-    const unsigned blocks = (unsigned)(n_heads * s.nsp + dim / (LA_WAVES * 4));
+    const unsigned blocks = (unsigned)(n_heads * s.nsp + dim / (LA_WAVES * la_ocols(s.slots)));
     static std::map<unsigned long long, int> occupancy;     // per instantiation and LDS size (the query is a host call)
     const unsigned long long key = ((unsigned long long)head_size << 48) | ((unsigned long long)(s.slots_kind * 16 + s.att) << 32) | smem;
     auto it = occupancy.find(key);
@@ -94,7 +96,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     }
     const int per_cu = it->second;
     // (split-context forms: the head's first chunk block waits for the other chunks' records -- one more waiter per head)
-    const long long waiters = dim / (LA_WAVES * 4) + (s.att >= 2 && s.att <= 4 ? n_heads : 0);
+    const long long waiters = dim / (LA_WAVES * la_ocols(s.slots)) + (s.att >= 2 && s.att <= 4 ? n_heads : 0);
     if (g_ao_guard && (long long)per_cu * stream_cu_count() < waiters + 1) return -1;
     return s.att;
 }
@@ -118,7 +120,7 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.sync = sync;
     a.nheads = n_heads;
     a.natt = n_heads * s.nsp;
-    a.no = dim / (LA_WAVES * 4);
+    a.no = dim / (LA_WAVES * la_ocols(s.slots));
 #ifdef Q4_PROFILING
     a.att.dbg = g_dbg ? g_dbg + 4096 * 4 : nullptr;      // per-wave cycle stamps of the attention role, behind the per-block records
     a.dbg = g_dbg;

@@ -39,11 +39,12 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 static inline int divUp(int a, int b) { return (a - 1) / b + 1; }   // common.h:80-82
 
 // bytes of RunState::att: n_heads * max(seq_len, dim) halves (the reference's n_heads * dim, llama2_q4.cu:46, overflows for
-// seq_len > dim), and at least the flash-decode partial records of the split-context attention at 128 positions per block
-// (one record of head_size + 4 floats per head and chunk; this build keeps no scores there)
+// seq_len > dim), and at least the flash-decode partial records of the split-context attention at 128 positions per block, eight
+// per head or more (one record of head_size + 4 floats per head and chunk; this build keeps no scores there)
 static inline size_t att_buffer_bytes(const Config* p) {
     const size_t ref = (size_t)p->n_heads * (p->seq_len > p->dim ? p->seq_len : p->dim) * sizeof(q4_half);
-    const size_t rec = (size_t)p->n_heads * divUp(p->seq_len, 128) * (size_t)(p->dim / p->n_heads + 4) * 8;   // {float, tag} granules
+    const int chunks = divUp(p->seq_len, 128) > 8 ? divUp(p->seq_len, 128) : 8;   // (bin 512 works with eight 64-position chunks)
+    const size_t rec = (size_t)p->n_heads * chunks * (size_t)(p->dim / p->n_heads + 4) * 8;   // {float, tag} granules
     return ref > rec ? ref : rec;
 }
 
