@@ -142,10 +142,14 @@ __global__ void convert_fp16_to_fp32_kernel(float* out, const q4_half* in, int e
 
 // argmax_kernel (gpu_kernels.h:448-493). Ties resolve to the LOWEST index (the reference's tie-break is a
 // benign race; lowest index is one of its legal outcomes and matches the oracle).
+// x_next != nullptr (greedy steps queued several per graph replay, q4_run_transformer_steps): the winner's embedding row is
+// copied into the residual stream right here -- the next step of the replay takes its token from this launch by construction, so
+// its copy_embedding launch (a PCIe read of the pinned token ring + a boundary) is left out of the graph
 __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size, int* result, volatile int* pPos,
-                                                      int* pPosGpu, int write_token) {
+                                                      int* pPosGpu, int write_token, q4_half* x_next, const q4_half* table, int dim) {
     __shared__ float sval[16];
     __shared__ int sidx[16];
+    __shared__ int s_token;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the position lives in HBM too (pPosGpu == *pPos by construction, :490-491): read that copy instead of
     // paying a PCIe round trip to the pinned host word on every token
@@ -181,6 +185,15 @@ __global__ void __launch_bounds__(1024) argmax_kernel(const q4_half* x, int size
         for (int w = 1; w < nw; w++)
             if (sval[w] > max_val || (sval[w] == max_val && sidx[w] < max_pos)) { max_val = sval[w]; max_pos = sidx[w]; }
         if (max_pos == 0x7fffffff) max_pos = 0;          // all NaN / -inf
+        s_token = max_pos;
+    }
+    if (x_next != nullptr) {                             // (uniform: a kernel argument)
+        __syncthreads();
+        const int token = s_token;
+        for (int u = tid; u < (dim >> 3); u += blockDim.x)
+            reinterpret_cast<u32x4*>(x_next)[u] = reinterpret_cast<const u32x4*>(table + (size_t)token * dim)[u];
+    }
+    if (tid == 0) {
         token_pos++;
         if (write_token) result[token_pos] = max_pos;    // :486-487
         __threadfence_system();                          // the host may be spinning on *pPos (q4_wait_pos)
@@ -465,10 +478,20 @@ __attribute__((visibility("hidden"))) int q4_copy_logits_at_pos(float* logits_ar
 }
 
 int q4_argmax(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, int write_token) {
-    Q4_LAUNCH(argmax_kernel, dim3(1), dim3(1024), 0, x, size, result, pPos, pPosGpu, write_token);
+    Q4_LAUNCH(argmax_kernel, dim3(1), dim3(1024), 0, x, size, result, pPos, pPosGpu, write_token, (q4_half*)nullptr, (const q4_half*)nullptr, 0);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
 
 }  // extern "C"
+
+namespace q4 {
+// argmax whose winner's embedding row becomes the next step's residual stream (see argmax_kernel)
+int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, q4_half* x_next, const q4_half* table, int dim) {
+    if (dim & 7) return Q4_ERR_UNSUPPORTED_SIZE;
+    Q4_LAUNCH(argmax_kernel, dim3(1), dim3(1024), 0, x, size, result, pPos, pPosGpu, 1, x_next, table, dim);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+}  // namespace q4
 

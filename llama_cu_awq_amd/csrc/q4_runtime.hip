@@ -447,7 +447,13 @@ static inline void arm_timing(int bit) {
 }
 #define Q4_UNLESS(bit, call) do { if (!(g_skip & (bit))) { if (g_time_mask) arm_timing(bit); int rc__ = (call); g_ev_start = g_ev_stop = nullptr; if (rc__) return rc__; } } while (0)
 
+static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding);
 int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin) {
+    return run_network(pPos, p, s, w, seq_len_bin, false);
+}
+// have_embedding: the preceding launch of the stream (the greedy sampler of the previous step, inside one graph replay) has left
+// the token's embedding row in s->x already
+static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding) {
     q4_half* x = s->x;
     const int dim = p->dim;
     const int hidden_dim = p->hidden_dim;
@@ -457,7 +463,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     const float2* rope_table = rope_table_of(s);
     unsigned* sync = sync_words_of(s);
 
-    Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
+    if (!have_embedding)
+        Q4_UNLESS(64, q4_copy_embedding(x, w->token_embedding_table, dim, s->shared_data->tokens, pPos));   // :294
 
     const size_t att_bytes = att_buffer_bytes(p);
     // :320-323 as ONE launch where the geometry, the bin and the stream's CUs admit it (layer_attn.h); the launch in front of it
@@ -652,11 +659,20 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             hipGraph_t graph = nullptr;
             Q4_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
             int rc = 0;
+            // generated tokens, several steps per replay: step i + 1 takes the token step i writes -- its sampler launch leaves the
+            // embedding row in s->x and the copy_embedding launch of step i + 1 is left out (the fused sequence only: level 0 is
+            // the reference's 1:1 launch list)
+            const bool feed = greedy && gen_token && nsteps > 1 && g_fusion >= 1;
             for (int i = 0; i < nsteps && !rc; i++) {
-                rc = q4_run_llama_network(s->pos, p, s, w, seq_len_bin);
+                rc = run_network(s->pos, p, s, w, seq_len_bin, feed && i > 0);
                 if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
-                if (!rc && greedy)
-                    rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+                if (!rc && greedy) {
+                    if (feed && i + 1 < nsteps)
+                        rc = launch_argmax_feed(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos,
+                                                s->x, w->token_embedding_table, p->dim);
+                    else
+                        rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+                }
             }
             hipError_t e = hipStreamEndCapture(g_stream, &graph);
             if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
