@@ -3,11 +3,12 @@
 //
 // Every launch of the decode step carries ~3-4 us that are not streaming (boundary, kernel arguments, first-data latency,
 // the x chain); attention and o-proj are the two latency-bound launches of a layer, so they share one: blocks [0, natt) are
-// the attention role -- one block per head, or per (head, chunk) in the split-context bins, exactly the stand-alone kernels'
-// bodies in 8-wave blocks --, the rest are the o-proj role (gemv_q4_body, 8 waves), which puts its weights in flight at entry,
-// polls ONE granule of the attention output, then reads the vector (every 8-byte {two halves, tag} granule validates itself
-// against the launch's epoch) and runs the dot products. The attention blocks publish with one store instruction per head
-// and never wait.
+// the attention role -- head_size / 32 blocks per head up to bin 256 (each: all scores of the head, one 64-byte slice of the V
+// rows; attention.h, VS), or one per (head, chunk) in the split-context bins; the stand-alone kernels' bodies in 8-wave blocks
+// --, the rest are the o-proj role (gemv_q4_body, 8 waves), which puts its weights in flight at entry, polls ONE granule of
+// the attention output, then reads the vector (every 8-byte {two halves, tag} granule validates itself against the launch's
+// epoch) and runs the dot products. The attention blocks publish with one store instruction each; below bin 512 they never wait
+// (in the split-context bins a head's first chunk block gathers the other chunks' records, which wait for nobody).
 //
 // What the protocol rests on:
 //  * forward progress: consumers wait only for producers, producers wait for nobody, and the launcher admits the form only
@@ -35,7 +36,7 @@ struct AttOprojArgs {
     AttArgs att;
     SplitArgs split;
     unsigned* sync;                  // hand-off words of the model (sync layout: q4_internal.h)
-    unsigned nheads, natt, no;       // heads, attention blocks (heads, or heads x chunks), o-proj blocks
+    unsigned nheads, natt, no;       // heads, attention blocks (heads x V slices, or heads x chunks), o-proj blocks
     unsigned long long* dbg;         // profiling build: [block][4] wall-clock stamps (entry, after the wait, end, role)
     int mute;                        // profiling build: the attention blocks do not publish (a real time-out for tests/prof_cases.py)
 };
