@@ -47,7 +47,9 @@ struct AttArgs {
 // 1300-1950 of a head block's 6300-9600 cycles at positions 100 / 220, tools/timeline_attn.py), and publishes that slice. No
 // merge and no hand-off between the blocks of a head; the scores, the statistics and the rounding points are the one-block
 // form's, only the fp32 order in which an output sums its positions differs (16 positions per instruction instead of 4).
-template <int LPR, int U, int NW, int FUSED, bool PAD = false, int VS = 1>
+// LB: positions the caller guarantees to exist whatever the position word says (bin 256 is entered at position 128): their K
+// rows are requested BEFORE the word has arrived -- 0.19 us of dependent latency off half of the K stream
+template <int LPR, int U, int NW, int FUSED, bool PAD = false, int VS = 1, int LB = 0>
 __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho, const int vs = 0) {
     static_assert(!PAD || !FUSED, "padded heads: stand-alone kernel only");
     static_assert(VS == 1 || (FUSED && LPR == 4 * VS && (U * (64 / LPR)) % 16 == 0), "V slices: fused role, 64-byte slices, whole wave instructions");
@@ -78,7 +80,26 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     const q4_half* kh = a.key_cache + hoff;
     const q4_half* vh = a.value_cache + hoff;
     if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
-    const int size = __builtin_amdgcn_readfirstlane(*a.pPos) + 1;     // wave-uniform by construction: descriptors below stay in SGPRs
+    constexpr int ULB = LB / stride;                         // wave instructions whose rows all lie below LB
+    static_assert(ULB <= U, "guaranteed rows: at most one register-resident group");
+    const unsigned row_bytes = (unsigned)kv_dim * 2u;
+    const unsigned lane_off = (unsigned)hoff * 2u;
+    u32x4 kv0[U], vv0[UV];
+    u32x4 qv;
+    int pos_word;
+    if constexpr (ULB > 0) {       // position word, q, then the guaranteed K rows: all in flight before the word is looked at
+        pos_word = *a.pPos;
+        qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + subc * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t rk_lb = __builtin_amdgcn_make_buffer_rsrc((void*)a.key_cache, 0, (unsigned)LB * row_bytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < ULB; u++)
+            kv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rk_lb, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        pos_word = *a.pPos;
+    }
+    const int size = __builtin_amdgcn_readfirstlane(pos_word) + 1;    // wave-uniform by construction: descriptors below stay in SGPRs
     if (STAMPS && a.dbg) { asm volatile("" :: "s"(size)); ts[1] = __builtin_readcyclecounter(); }
 
     // ---- the first group's K AND V rows go out together: one memory latency for the whole kernel at context <= `group`
@@ -90,16 +111,13 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     // dependent round trips, ~2 us (s_memtime stamps, tools/timeline_attn.py). Rows past the position are not requested at all:
     // requesting the whole bin ahead of the position word, to save that dependent latency, was measured 22-31 us per token
     // SLOWER at 7B -- the bytes cost more.
-    u32x4 qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + subc * 8);
+    if constexpr (ULB == 0) qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + subc * 8);
     if (PAD && !lane_on) qv = (u32x4){0u, 0u, 0u, 0u};
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned row_bytes = (unsigned)kv_dim * 2u;
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)a.key_cache, 0, (unsigned)size * row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.value_cache, 0, (unsigned)size * row_bytes, 0x00020000);
-    const unsigned lane_off = (unsigned)hoff * 2u;
-    u32x4 kv0[U], vv0[UV];
 #pragma unroll
-    for (int u = 0; u < U; u++)
+    for (int u = ULB; u < U; u++)
         kv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (VS > 1) {      // lane = (position lane >> 2 of 16, 16-byte piece lane & 3 of the block's 64-byte slice)

@@ -49,6 +49,7 @@ struct AttShape {
     static constexpr int CHUNK = ATT == 4 ? 64 : ATT == 0 || ATT == 2 || ATT == 5 ? 128 : 256;
     static constexpr int U = CHUNK / (LA_WAVES * (64 / LPR));
     static constexpr int VS = ATT >= 5 ? LPR / 4 : 1;
+    static constexpr int LB = ATT == 1 || ATT == 6 ? 128 : 0;   // forms entered above position 127 only (bins > 128)
 };
 
 template <int SLOTS, bool HALF, int ATT, int LPR>
@@ -78,8 +79,8 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const At
 #endif
     if (b < a.natt) {
         ho.pub = g_att;
-        if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2>(a.att, (int)b, ho);
-        else if constexpr (ATT >= 5) attention_body<LPR, U, NW, 2, false, AttShape<LPR, ATT>::VS>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
+        if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2, false, 1, AttShape<LPR, ATT>::LB>(a.att, (int)b, ho);
+        else if constexpr (ATT >= 5) attention_body<LPR, U, NW, 2, false, AttShape<LPR, ATT>::VS, AttShape<LPR, ATT>::LB>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
         else attention_split_body<LPR, U, true, NW>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
     } else {
         const unsigned j = b - a.natt;
