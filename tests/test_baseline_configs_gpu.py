@@ -139,11 +139,12 @@ def _kv_to_host(q4, t):
     return k, v
 
 
-@pytest.mark.parametrize("target", [400, 900, 1100, 2040])
+@pytest.mark.parametrize("target", [200, 400, 900, 1100, 2040])
 def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target, observed):
-    """Decode `target` positions through run_transformer's captured graphs (every sequence-length bin up to 2048, the
-    split-context attention from bin 1024 on), then compare ONE more step with the restatement started from the GPU's
-    own KV cache -- no 2000-step CPU run, and every cached position takes part in the compared step's attention."""
+    """Decode `target` positions through run_transformer's captured graphs (every sequence-length bin up to 2048: bin 256 with
+    four attention blocks per head, one V slice each, the split-context attention from bin 512 on), then compare ONE more
+    step with the restatement started from the GPU's own KV cache -- no 2000-step CPU run, and every cached position takes
+    part in the compared step's attention."""
     L = q4.lib()
     assert L.q4_get_fusion() == q4.DEFAULT_FUSION
     t = q4.Transformer(m7b)
@@ -155,7 +156,7 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     np.ctypeslib.as_array(m.L.orc_key_cache(m.h), shape=(n,))[:] = k
     np.ctypeslib.as_array(m.L.orc_value_cache(m.h), shape=(n,))[:] = v
     tok = int(t.token(target))
-    t.run_transformer(True)                                       # position `target`, graph of its bin (512 / 1024 / 2048)
+    t.run_transformer(True)                                       # position `target`, graph of its bin (256 / 512 / 1024 / 2048)
     q4.synchronize()
     got = t.logits()
     ref = m.forward(tok, target)
