@@ -139,16 +139,15 @@ def _kv_to_host(q4, t):
     return k, v
 
 
-@pytest.mark.parametrize("target", [200, 400, 900, 1100, 2040])
-def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target, observed):
+def _step_from_the_gpus_cache(q4, orc, path, target, observed, key):
     """Decode `target` positions through run_transformer's captured graphs (every sequence-length bin up to 2048: bin 256 with
     four attention blocks per head, one V slice each, the split-context attention from bin 512 on), then compare ONE more
     step with the restatement started from the GPU's own KV cache -- no 2000-step CPU run, and every cached position takes
     part in the compared step's attention."""
     L = q4.lib()
     assert L.q4_get_fusion() == q4.DEFAULT_FUSION
-    t = q4.Transformer(m7b)
-    m = orc.Model(m7b)
+    t = q4.Transformer(path)
+    m = orc.Model(path)
     toks, tps, timed, _ = t.generate_ids(PROMPT, target)          # positions 0 .. target-1 (graphs of 128 .. 2048)
     assert timed == target - 1 and t.pos() == target
     k, v = _kv_to_host(q4, t)
@@ -163,7 +162,7 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
     assert t.pos() == target + 1
     # layer 0's K/V row depends on the embedding only; layer 1's on layer 0's attention over all `target` cached positions
     rk, rv = m.kv()
-    rec = observed.setdefault("config4_7b_pos%d" % target, {"tok_s_to_target": tps})
+    rec = observed.setdefault("%s_pos%d" % (key, target), {"tok_s_to_target": tps})
     # K rows carry RoPE at a large angle (two 1-ulp GEMV outputs rotated: up to 4 fp16 ulps), V rows are one GEMV deep
     for layer, ktol, vtol in ((0, 8e-3, 3e-3), (1, 2.4e-2, 1.2e-2), (t.config.n_layers - 1, 0.1, 0.1)):
         gk, gv = t.kv_row(layer, target)
@@ -179,6 +178,17 @@ def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, ta
         assert int(t.token(target + 1)) == int(np.argmax(r32))
     t.close()
     m.close()
+
+
+@pytest.mark.parametrize("target", [200, 400, 900, 1100, 2040])
+def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target, observed):
+    _step_from_the_gpus_cache(q4, orc, m7b, target, observed, "config4_7b")
+
+
+def test_llama2_13b_inside_bin_256(q4, orc, observed):
+    """The same comparison at the 13B geometry inside bin 256 (K = 5120 in three k-slots with a shared half slot, 40 heads x
+    4 V-slice attention blocks, 160 o-proj blocks)."""
+    _step_from_the_gpus_cache(q4, orc, _model("13b"), 200, observed, "config3_13b")
 
 
 def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b, observed):
