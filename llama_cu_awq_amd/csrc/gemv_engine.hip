@@ -1,0 +1,313 @@
+// gemv_engine.hip -- the int4 GEMV as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill",
+// "nt-weights", "engine-vs-launches"). Replaces, for the shapes it covers, rmsnorm_kernel + ffn_matvec_silu_kernel
+// (gpu_kernels.h:72-105, 256-275) exactly like gemv_q4_kernel<MODE_FFN> does, bit for bit.
+//
+// Why another form: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded
+// by its VGPRs, no weight request can go out before the x chain of its block has been scheduled around, and every launch
+// pays ~2 us of front. Here one block per CU owns a contiguous range of column quads, and inside it
+//   * ONE loader wave streams that range with `buffer_load_dwordx4 ... nt lds` (1 KiB per instruction, straight into an
+//     8 x 16 KiB LDS ring; no VGPR ever holds a weight on the way in). It starts at t = 0 -- the x chain and the weight stream
+//     overlap by construction -- and runs ahead of the consumers by the depth of the ring;
+//   * EIGHT consumer waves stage x (fused rmsnorm, the canonical reduction of q4_device.h), keep their 32 registers of permuted
+//     x for the whole kernel, and retire one ring slot together: wave w multiplies column w/2 of the quad for matrix w%2
+//     (gate / up), both k-slots, with the denormal-nibble v_dot2c body of gemv_q4.h.
+// A ring slot = one column quad = 4 columns x 2 matrices x K/8 bytes (16 KiB at K = 4096), contiguous per matrix in HBM
+// (QWeight is column-major per output column: consecutive columns follow each other), so a fill is 16 fully coalesced
+// 1 KiB pieces. Scales and zeros of the block's whole range (7 KiB) are fetched once, by the same loader, in front of the ring.
+//
+// Synchronisation inside the block (no s_barrier after the entry one: the loader must never wait for a consumer's pace):
+//   landed   (LDS word) fills the loader KNOWS complete: after issuing fill j it waits vmcnt(16 * LAG) -- loads return in order,
+//            so fills <= j - LAG have landed -- and stores j + 1 - LAG; at the end it drains LAG-1 .. 0.
+//   consumed (LDS word) += 1 by each consumer wave once its ds_reads of a slot have returned; the loader refills slot j % 8
+//            when consumed >= 8 * (j - 7).
+//   consumer-only barriers of the x chain: one LDS counter each.
+// vmcnt is a 6-bit counter, so a wave has at most 64 KiB of 1 KiB pieces in flight: LAG <= 3.
+#include "gemv_q4.h"
+
+namespace q4 {
+
+int g_engine = 0;   // 0: gemv_q4_kernel<MODE_FFN>; 1..3: the engine with LAG = value, where the shape is covered
+
+constexpr int ENG_RING = 8, ENG_NQMAX = 12, ENG_STAGERS = 8;   // ring slots; quads per block; waves that stage x (K / 8 chunks = 512 threads)
+
+template <int KSL>
+struct EngLds {
+    static constexpr unsigned SLOT = 8u * KSL * 1024u;                 // 4 columns x 2 matrices x KSL KiB
+    static constexpr unsigned RING = 0;
+    static constexpr unsigned SIDE_S_BYTES = ((ENG_NQMAX * 128u * KSL) + 1023u) & ~1023u;   // per matrix: quad = 4 cols x 16 KSL groups x 2 B
+    static constexpr unsigned SIDE_S = RING + ENG_RING * SLOT;
+    static constexpr unsigned SIDE_Z_BYTES = 1024u;                    // per matrix: quad = 4 cols x 2 KSL words x 4 B (<= 1 KiB for KSL <= 2)
+    static constexpr unsigned SIDE_Z = SIDE_S + 2 * SIDE_S_BYTES;
+    static constexpr unsigned XS = SIDE_Z + 2 * SIDE_Z_BYTES;          // [KSL][4][64] x 16 B permuted x
+    static constexpr unsigned SX = XS + KSL * 4096u;                   // [KSL][64] -(sum of the 32 x) * 2^-20
+    static constexpr unsigned PART = SX + KSL * 256u;                  // [KSL * 256] rmsnorm chunk partials
+    static constexpr unsigned TOT = PART + KSL * 1024u;                // [NQMAX][8] column totals
+    static constexpr unsigned FLAGS = TOT + ENG_NQMAX * 32u;           // landed, consumed, three consumer barriers
+    static constexpr unsigned BYTES = FLAGS + 64u;
+    static_assert(ENG_NQMAX * 32u * KSL <= SIDE_Z_BYTES, "zeros of the block's range: one DMA instruction per matrix");
+};
+enum { F_LANDED = 0, F_BAR0 = 1, F_BAR1 = 2, F_BAR2 = 3, F_CONS0 = 8 };   // [F_CONS0 + s]: units of ring slot s read so far (8 per fill)
+
+// one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
+// M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
+__device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Flag words in LDS. A wave's LDS operations execute in program order, so "write data, then bump the flag" and "see the flag, then
+// read data" need no hardware fence inside a workgroup; the relaxed forms + compiler barriers keep hipcc from re-ordering them AND
+// from attaching its own waits: for an acquire / release at workgroup scope it emits s_waitcnt vmcnt(0) here (it cannot see the
+// asm LDS-DMA pieces, but it counts the x loads at the kernel's entry), which would drain the loader's stream at every flag.
+__device__ __forceinline__ unsigned lds_peek(unsigned* p) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_post(unsigned* p, unsigned v, unsigned lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// every wait is bounded (~0.2 s): a protocol error must end as wrong numbers in a test, never as a hung GPU
+constexpr unsigned ENG_SPIN_LIMIT = 1u << 21;
+__device__ __forceinline__ void lds_wait_ge(unsigned* p, unsigned target) {
+    for (unsigned n = 0; lds_peek(p) < target && n < ENG_SPIN_LIMIT; n++) __builtin_amdgcn_s_sleep(1);
+}
+// barrier among the nc consumer waves only (the loader keeps issuing)
+__device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, unsigned nc) {
+    lds_bump(cnt, lane);
+    lds_wait_ge(cnt, nc);
+}
+
+// profiling build: wall-clock stamps (100 MHz, the same counter on every XCD) of one block's loader and of its consumer wave 0,
+// 64 words per block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry,
+// [17] x staged, [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored
+#ifdef Q4_PROFILING
+#define ENG_STAMP(k) do { if (a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
+#else
+#define ENG_STAMP(k) do { } while (0)
+#endif
+
+template <int KSL, bool NORM, int LAG, int NC>
+__global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArgs a, const unsigned qbase, const unsigned qrem) {
+    static_assert(KSL == 2, "x staging: one 8-half chunk per consumer thread (K = 4096)");
+    static_assert(LAG >= 1 && 8 * KSL * LAG <= 48, "vmcnt is 6 bits");
+    static_assert(NC >= ENG_STAGERS && NC <= 15, "the stagers are consumer waves; 1024 threads per block");
+    using L = EngLds<KSL>;
+    constexpr int PIECES = 4 * KSL;              // 1 KiB pieces per matrix and quad
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + L::FLAGS);
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block b owns column quads [q0, q0 + nq): N / 4 quads dealt out evenly, the first qrem blocks take one more
+    const unsigned q0 = blockIdx.x * qbase + (blockIdx.x < qrem ? blockIdx.x : qrem);
+    const int nq = (int)(qbase + (blockIdx.x < qrem ? 1u : 0u));
+
+    // The two roles part BEFORE any vector load: after a join hipcc would make the loader wait (vmcnt(0)) for the consumers' x loads
+    // wherever it re-uses one of their registers. Both paths meet the entry barrier once (the hardware counts arrivals, not sites).
+    if (wave == NC) {
+        if (lane < 16u) flags[lane] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // flags are zero, and the consumers' x loads are queued on this CU
+        // ---------------------------------------------------------------- loader
+        __builtin_amdgcn_s_setprio(3);
+        ENG_STAMP(0);
+        const unsigned voff = lane * 16u;
+        __amdgpu_buffer_rsrc_t rw[2], rs[2], rz[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            rw[m] = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].w, 0, a.N * a.pw4 * 16, 0x00020000);
+            rz[m] = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
+            rs[m] = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
+        }
+        // scales and zeros of quads [q0, q1): contiguous per matrix; lanes past the tensor's end read nothing
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+#pragma unroll
+            for (unsigned i = 0; i < L::SIDE_S_BYTES / 1024u; i++)
+                dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + i * 1024u, voff, rs[m], q0 * (128u * KSL) + i * 1024u);
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rz[m], q0 * (32u * KSL));
+        }
+        ENG_STAMP(1);
+        for (int j = 0; j < nq; j++) {
+            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONS0 + j % ENG_RING], 8u * (unsigned)(j / ENG_RING));   // the slot's previous fill has been read
+            const unsigned slot = L::RING + (unsigned)(j % ENG_RING) * L::SLOT;
+            const unsigned soff = (q0 + (unsigned)j) * (L::SLOT / 2u);
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int p = 0; p < PIECES; p++)
+                    dma_piece(slot + (unsigned)(m * PIECES + p) * 1024u, voff, rw[m], soff + (unsigned)p * 1024u);
+            wait_vmcnt<2 * PIECES * LAG>();          // fills <= j - LAG have landed
+            if (j + 1 - LAG > 0) { lds_post(&flags[F_LANDED], (unsigned)(j + 1 - LAG), lane); ENG_STAMP(2 + j - LAG); }
+        }
+        if (LAG > 2) { wait_vmcnt<2 * PIECES * 2>(); if (nq - 2 > 0) { lds_post(&flags[F_LANDED], (unsigned)(nq - 2), lane); ENG_STAMP(2 + nq - 3); } }
+        if (LAG > 1) { wait_vmcnt<2 * PIECES * 1>(); if (nq - 1 > 0) { lds_post(&flags[F_LANDED], (unsigned)(nq - 1), lane); ENG_STAMP(2 + nq - 2); } }
+        wait_vmcnt<0>();
+        lds_post(&flags[F_LANDED], (unsigned)nq, lane);
+        ENG_STAMP(2 + nq - 1);
+        ENG_STAMP(15);
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumers
+    // the stagers' x loads go out in front of everything the loader will queue on this CU (the vector-memory path returns in order)
+    const bool stager = wave < ENG_STAGERS;
+    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
+    if (stager) {
+        xraw = reinterpret_cast<const u32x4*>(a.x)[tid];
+        if (NORM) wraw = reinterpret_cast<const u32x4*>(a.rms_w)[tid];
+    }
+    asm volatile("s_barrier" ::: "memory");   // nobody waits for a vector load here
+    if (wave == 0) ENG_STAMP(16);
+    u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
+    float* sx = reinterpret_cast<float*>(smem + L::SX);
+    float* part = reinterpret_cast<float*>(smem + L::PART);
+    float* tot = reinterpret_cast<float*>(smem + L::TOT);
+    {   // x chain: the staging of gemv_q4_body (stage_tail), one chunk per stager thread
+        float ss = 1.f;
+        if (NORM) {
+            if (stager) part[tid] = sumsq8(xraw, 0.f);
+            consumer_barrier(&flags[F_BAR0], lane, NC);
+            if (stager) ss = rms_scale_from_partials<KSL * 256>(part, KSL * 256, a.K);
+        }
+        if (stager) {
+            u32x4 v = xraw;
+            if (NORM) v = rms_apply8(v, wraw, ss);
+            const u32x4 pv = permute_x8(v);
+            const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+            float cb = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum: the 32 inputs of one uint4 unit
+            const unsigned j = tid >> 2, d = tid & 3u;
+            xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+            if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
+        }
+        consumer_barrier(&flags[F_BAR1], lane, NC);
+    }
+    if (wave == 0) ENG_STAMP(17);
+    u32x4 X[KSL][4];
+    float corr[KSL];
+#pragma unroll
+    for (int ks = 0; ks < KSL; ks++) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lane];
+        corr[ks] = sx[ks * 64 + lane];
+    }
+    // Work units: one (quad, matrix, column) = both k-slots of one column = 2 KiB of a ring slot; unit u = quad * 8 + matrix * 4 +
+    // column, dealt round-robin to the NC consumer waves (every wave holds all of x, so any wave can take any unit). A wave's
+    // units of one group of four are reduced together (the transposing reduce of gemv_q4.h leaves unit r's total in DPP row r).
+    const int nunits = nq * 8;
+    const unsigned zsh = ((lane >> 2) & 7u) * 4u;      // nibble of this lane's group in its zeros word (16 groups per k-slot)
+    for (int u0 = wave; u0 < nunits; u0 += 4 * NC) {
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int u = u0 + r * NC;
+            if (u < nunits) {
+                const int i = u >> 3, mat = (u >> 2) & 1, col = u & 3;
+                lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u);
+                if (wave == 0 && r == 0) ENG_STAMP(18 + (u0 / (4 * NC)));
+                const unsigned char* sl = smem + L::RING + (unsigned)(i % ENG_RING) * L::SLOT + (unsigned)((mat * 4 + col) * KSL) * 1024u + lane * 16u;
+                const unsigned char* side_s = smem + L::SIDE_S + mat * L::SIDE_S_BYTES;
+                const unsigned char* side_z = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES;
+                u32x4 W[KSL];
+                unsigned zw[KSL];
+                uint16_t sc[KSL];
+#pragma unroll
+                for (int ks = 0; ks < KSL; ks++) {
+                    const unsigned grp = (unsigned)ks * 16u + (lane >> 2);          // quantisation group of unit ks * 64 + lane
+                    W[ks] = *reinterpret_cast<const u32x4*>(sl + ks * 1024);
+                    sc[ks] = *reinterpret_cast<const uint16_t*>(side_s + ((unsigned)(i * 4 + col) * (16u * KSL) + grp) * 2u);
+                    zw[ks] = *reinterpret_cast<const unsigned*>(side_z + ((unsigned)(i * 4 + col) * (2u * KSL) + (grp >> 3)) * 4u);
+                }
+                // the ring slot is free once all 8 of its units have been read (LDS order: the bump follows the reads)
+                lds_bump(&flags[F_CONS0 + i % ENG_RING], lane);
+                float c = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSL; ks++) {
+                    const u32x4 w = W[ks];
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d];
+                        const unsigned tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[ks][d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[ks][d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[ks][d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[ks][d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((zw[ks] >> zsh) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr[ks], t);
+                    c = __builtin_fmaf(h2f(sc[ks]), t, c);
+                }
+                cs[r] = c;
+            }
+        }
+        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit u0 + r * NC
+        const int ur = u0 + (int)(lane >> 4) * NC;
+        if ((lane & 15u) == 0 && ur < nunits) tot[ur] = total;
+        if (wave == 0) { ENG_STAMP(31 + (u0 / (4 * NC))); }
+    }
+    consumer_barrier(&flags[F_BAR2], lane, NC);
+    if (wave == 0) ENG_STAMP(44);
+    if ((int)tid < nq * 4) {
+        const int i = tid >> 2, c = tid & 3;
+        const float g = tot[i * 8 + c], u = tot[i * 8 + 4 + c];
+        float val = g;
+        val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
+        val *= u;                                       // :272
+        a.out[0][(q0 + i) * 4 + c] = f2h(val);
+    }
+    if (wave == 0) ENG_STAMP(45);
+}
+
+// the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU.
+// g_engine = lag (1..3) + 4 * consumer-wave choice (0: 8, 1: 15, 2: 12)
+bool ffn_engine_covers(const GemvArgs& a) {
+    return g_engine >= 1 && (g_engine & 3) != 0 && (g_engine >> 2) <= 2 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+           divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count();
+}
+
+template <int KSL, bool NORM, int LAG, int NC>
+static int launch_engine(const GemvArgs& a) {
+    static bool opted = false;
+    if (!opted) {
+        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EngLds<KSL>::BYTES));
+        opted = true;
+    }
+    const unsigned nquads = (unsigned)a.N >> 2, nb = (unsigned)cu_count();
+    Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, NC>), dim3(nb), dim3((NC + 1) * 64), EngLds<KSL>::BYTES, a, nquads / nb, nquads % nb);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+
+template <int NC>
+static int launch_engine_nc(const GemvArgs& a) {
+    const bool norm = a.rms_w != nullptr;
+    switch (g_engine & 3) {
+        case 1: return norm ? launch_engine<2, true, 1, NC>(a) : launch_engine<2, false, 1, NC>(a);
+        case 2: return norm ? launch_engine<2, true, 2, NC>(a) : launch_engine<2, false, 2, NC>(a);
+        default: return norm ? launch_engine<2, true, 3, NC>(a) : launch_engine<2, false, 3, NC>(a);
+    }
+}
+
+int launch_ffn_engine(const GemvArgs& a) {
+    switch (g_engine >> 2) {
+        case 0: return launch_engine_nc<8>(a);
+        case 1: return launch_engine_nc<15>(a);
+        default: return launch_engine_nc<12>(a);
+    }
+}
+
+}  // namespace q4

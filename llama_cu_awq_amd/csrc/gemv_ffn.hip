@@ -1,7 +1,10 @@
 // gemv_ffn.hip -- instantiations of the int4 GEMV for ffn_matvec_silu_kernel (gpu_kernels.h:256-275)
 #include "gemv_q4.h"
 namespace q4 {
+bool ffn_engine_covers(const GemvArgs& a);   // gemv_engine.hip: loader / consumer form on LDS-DMA
+int launch_ffn_engine(const GemvArgs& a);
 int launch_gemv_ffn(const GemvArgs& a, int cols, int waves) {
+    if (ffn_engine_covers(a)) return launch_ffn_engine(a);
 #define Q4_CASE(S, C) if (slots == S && cols == C) { \
         return a.rms_w ? launch_one<MODE_FFN, S, C, true>(a, waves) : launch_one<MODE_FFN, S, C, false>(a, waves); }
     const int slots = pick_slots(a.nslots);

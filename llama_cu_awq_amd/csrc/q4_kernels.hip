@@ -288,6 +288,7 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 7) g_multi_steps = slots;
     if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
+    if (kind == 11) g_engine = slots;       // gate/up GEMV: 0 = gemv_q4_kernel, 1..3 = loader / consumer engine with that vmcnt lag
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
 }

@@ -70,14 +70,19 @@ def algorithmic(kernel, model, ntok):
     if kernel.startswith("gemv_f16_kernel"):
         return v * d * 2 + d * 2 + v * 2
     if kernel.startswith("attention_oproj_kernel"):
-        # o-proj QWeight + residual in / out + q + attention output + K and V rows of positions 0..pos, averaged over the
-        # positions this form serves in an EAGER -n ntok run (form = third template argument; without graphs the network is
-        # launched with the exact context length instead of the bin: 0 up to 128, 1 up to 511, 4 at 512, 2 up to 1024, 3 above)
+        # o-proj QWeight + residual in / out + q + attention output + K and V rows of the context, averaged over the context
+        # lengths this form serves in an EAGER -n ntok run. form = third template argument; without graphs the network is launched
+        # with the exact context length instead of the bin (layer_attn.hip, ao_shape): 5 = V-slice blocks up to 128 positions,
+        # 6 = V-slice blocks 129..256, 1 = one block per head 257..511, 4 = 64-position chunks at exactly 512, 2 = 128-position
+        # chunks 513..1024, 3 = 256-position chunks above; 0 = one block per head up to 128 (V-slice form switched off)
         m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel)
-        form = int(m.group(1)) if m else 0
-        lo, hi = {0: (0, 128), 1: (128, 511), 2: (512, 1024), 3: (1024, 2048), 4: (511, 512)}.get(form, (0, ntok))
+        form = int(m.group(1)) if m else -1
+        ranges = {0: (1, 128), 5: (1, 128), 6: (129, 256), 1: (257, 511), 4: (512, 512), 2: (513, 1024), 3: (1025, 2048)}
+        if form not in ranges:
+            raise SystemExit("attention_oproj_kernel form %d has no context range in summarize_profiles.py: %s" % (form, kernel))
+        lo, hi = ranges[form]
         hi = min(hi, ntok)
-        avg_rows = (lo + hi + 1) / 2.0
+        avg_rows = (lo + hi) / 2.0
         return int(qweight_bytes(d, d) + 4 * d * 2 + avg_rows * 2 * d * 2)
     return None
 
@@ -104,6 +109,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
         if alg:
             e["algorithmic_bytes_per_launch"] = alg
             e["traffic_over_algorithmic"] = round(e["traffic_bytes_per_launch"] / alg, 4)
+            # a launch cannot move fewer bytes than its algorithm needs: a ratio below 1 means the byte model above is wrong
+            assert e["traffic_over_algorithmic"] >= 0.98, (k, model, ntok, e)
     traffic["%s_n%d" % (model, ntok)] = per
     print(model, ntok, json.dumps(per)[:600])
 if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
