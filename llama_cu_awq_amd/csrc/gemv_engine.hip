@@ -1,34 +1,41 @@
-// gemv_engine.hip -- the int4 GEMV as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill",
-// "nt-weights", "engine-vs-launches"). Replaces, for the shapes it covers, rmsnorm_kernel + ffn_matvec_silu_kernel
-// (gpu_kernels.h:72-105, 256-275) exactly like gemv_q4_kernel<MODE_FFN> does, bit for bit.
+// gemv_engine.hip -- EXPERIMENT, profiling build only (q4_set_gemv_early(11, lag)): the fused gate/up GEMV as a loader / consumer
+// engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as
+// gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit.
+// The shipped library does not contain it: measured on MI355X (profiles/r04_engine_*.txt) it streams at
+// 7.5 TB/s and still ends where the shipped kernel ends, because the int4 dequant-dot is VALU work, not bandwidth.
 //
-// Why another form: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded
-// by its VGPRs, no weight request can go out before the x chain of its block has been scheduled around, and every launch
-// pays ~2 us of front. Here one block per CU owns a contiguous range of column quads, and inside it
+// Idea: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded by its VGPRs, no
+// weight request goes out before the x chain of its block has been scheduled around, and every block re-stages x. Here one block
+// per CU owns a contiguous range of column quads, and inside it
 //   * ONE loader wave streams that range with `buffer_load_dwordx4 ... nt lds` (1 KiB per instruction, straight into an
 //     8 x 16 KiB LDS ring; no VGPR ever holds a weight on the way in). It starts at t = 0 -- the x chain and the weight stream
 //     overlap by construction -- and runs ahead of the consumers by the depth of the ring;
-//   * EIGHT consumer waves stage x (fused rmsnorm, the canonical reduction of q4_device.h), keep their 32 registers of permuted
-//     x for the whole kernel, and retire one ring slot together: wave w multiplies column w/2 of the quad for matrix w%2
+//   * EIGHT consumer waves stage x once per CU (fused rmsnorm, the canonical reduction of q4_device.h), keep their 32 registers of
+//     permuted x for the whole kernel, and retire one ring slot together: wave w multiplies column w/2 of the quad for matrix w%2
 //     (gate / up), both k-slots, with the denormal-nibble v_dot2c body of gemv_q4.h.
 // A ring slot = one column quad = 4 columns x 2 matrices x K/8 bytes (16 KiB at K = 4096), contiguous per matrix in HBM
 // (QWeight is column-major per output column: consecutive columns follow each other), so a fill is 16 fully coalesced
 // 1 KiB pieces. Scales and zeros of the block's whole range (7 KiB) are fetched once, by the same loader, in front of the ring.
+// (tools/t_ldsdma.hip pins the instruction's semantics on gfx950: LDS address = M0 + immediate offset + lane * 16, M0 takes the
+// full 160 KiB range.)
 //
 // Synchronisation inside the block (no s_barrier after the entry one: the loader must never wait for a consumer's pace):
 //   landed   (LDS word) fills the loader KNOWS complete: after issuing fill j it waits vmcnt(16 * LAG) -- loads return in order,
-//            so fills <= j - LAG have landed -- and stores j + 1 - LAG; at the end it drains LAG-1 .. 0.
-//   consumed (LDS word) += 1 by each consumer wave once its ds_reads of a slot have returned; the loader refills slot j % 8
+//            so fills <= j - LAG have landed -- and stores j + 1 - LAG; at the end it drains LAG-1 .. 0. vmcnt is a 6-bit
+//            counter, so a wave has at most 64 KiB of 1 KiB pieces in flight: LAG <= 3, and what the loader may have in flight
+//            is exactly what it cannot know to have landed.
+//   consumed (LDS word) += 1 by each consumer wave once its ds_reads of a slot have been executed; the loader refills slot j % 8
 //            when consumed >= 8 * (j - 7).
 //   consumer-only barriers of the x chain: one LDS counter each.
-// vmcnt is a 6-bit counter, so a wave has at most 64 KiB of 1 KiB pieces in flight: LAG <= 3.
 #include "gemv_q4.h"
 
 namespace q4 {
 
 int g_engine = 0;   // 0: gemv_q4_kernel<MODE_FFN>; 1..3: the engine with LAG = value, where the shape is covered
 
-constexpr int ENG_RING = 8, ENG_NQMAX = 12, ENG_STAGERS = 8;   // ring slots; quads per block; waves that stage x (K / 8 chunks = 512 threads)
+#ifdef Q4_PROFILING
+
+constexpr int ENG_CONSUMERS = 8, ENG_RING = 8, ENG_NQMAX = 12;
 
 template <int KSL>
 struct EngLds {
@@ -46,7 +53,7 @@ struct EngLds {
     static constexpr unsigned BYTES = FLAGS + 64u;
     static_assert(ENG_NQMAX * 32u * KSL <= SIDE_Z_BYTES, "zeros of the block's range: one DMA instruction per matrix");
 };
-enum { F_LANDED = 0, F_BAR0 = 1, F_BAR1 = 2, F_BAR2 = 3, F_CONS0 = 8 };   // [F_CONS0 + s]: units of ring slot s read so far (8 per fill)
+enum { F_LANDED = 0, F_CONSUMED = 1, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4 };
 
 // one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
 // M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
@@ -79,29 +86,27 @@ __device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
 }
 // every wait is bounded (~0.2 s): a protocol error must end as wrong numbers in a test, never as a hung GPU
 constexpr unsigned ENG_SPIN_LIMIT = 1u << 21;
-__device__ __forceinline__ void lds_wait_ge(unsigned* p, unsigned target) {
-    for (unsigned n = 0; lds_peek(p) < target && n < ENG_SPIN_LIMIT; n++) __builtin_amdgcn_s_sleep(1);
+__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target) {
+    unsigned v = lds_peek(p);
+    for (unsigned n = 0; v < target && n < ENG_SPIN_LIMIT; n++) { __builtin_amdgcn_s_sleep(1); v = lds_peek(p); }
+    return v;
 }
-// barrier among the nc consumer waves only (the loader keeps issuing)
-__device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, unsigned nc) {
+// barrier among the consumer waves only (the loader keeps issuing)
+__device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane) {
     lds_bump(cnt, lane);
-    lds_wait_ge(cnt, nc);
+    lds_wait_ge(cnt, (unsigned)ENG_CONSUMERS);
 }
 
-// profiling build: wall-clock stamps (100 MHz, the same counter on every XCD) of one block's loader and of its consumer wave 0,
-// 64 words per block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry,
-// [17] x staged, [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored
-#ifdef Q4_PROFILING
-#define ENG_STAMP(k) do { if (a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
-#else
-#define ENG_STAMP(k) do { } while (0)
-#endif
+// wall-clock stamps (100 MHz, the same counter on every XCD) of one block's loader and of its consumer wave 0, 64 words per
+// block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry, [17] x staged,
+// [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored (tools/timeline_engine.py).
+// A stamp is a global store: it counts in the loader's vmcnt, so stamped runs of LAG = 1 stall on their own stamps.
+#define ENG_STAMP(k) do { if (STAMPS && a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
 
-template <int KSL, bool NORM, int LAG, int NC>
-__global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArgs a, const unsigned qbase, const unsigned qrem) {
+template <int KSL, bool NORM, int LAG, bool STAMPS>
+__global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(const GemvArgs a, const unsigned qbase, const unsigned qrem) {
     static_assert(KSL == 2, "x staging: one 8-half chunk per consumer thread (K = 4096)");
     static_assert(LAG >= 1 && 8 * KSL * LAG <= 48, "vmcnt is 6 bits");
-    static_assert(NC >= ENG_STAGERS && NC <= 15, "the stagers are consumer waves; 1024 threads per block");
     using L = EngLds<KSL>;
     constexpr int PIECES = 4 * KSL;              // 1 KiB pieces per matrix and quad
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
 
     // The two roles part BEFORE any vector load: after a join hipcc would make the loader wait (vmcnt(0)) for the consumers' x loads
     // wherever it re-uses one of their registers. Both paths meet the entry barrier once (the hardware counts arrivals, not sites).
-    if (wave == NC) {
+    if (wave == ENG_CONSUMERS) {
         if (lane < 16u) flags[lane] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // flags are zero, and the consumers' x loads are queued on this CU
         // ---------------------------------------------------------------- loader
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
             rz[m] = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
             rs[m] = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
         }
-        // scales and zeros of quads [q0, q1): contiguous per matrix; lanes past the tensor's end read nothing
+        // scales and zeros of quads [q0, q0 + nq): contiguous per matrix; lanes past the tensor's end read nothing
 #pragma unroll
         for (int m = 0; m < 2; m++) {
 #pragma unroll
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
         }
         ENG_STAMP(1);
         for (int j = 0; j < nq; j++) {
-            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONS0 + j % ENG_RING], 8u * (unsigned)(j / ENG_RING));   // the slot's previous fill has been read
+            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONSUMED], (unsigned)(ENG_CONSUMERS * (j - ENG_RING + 1)));
             const unsigned slot = L::RING + (unsigned)(j % ENG_RING) * L::SLOT;
             const unsigned soff = (q0 + (unsigned)j) * (L::SLOT / 2u);
 #pragma unroll
@@ -159,40 +164,35 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
     }
 
     // -------------------------------------------------------------------- consumers
-    // the stagers' x loads go out in front of everything the loader will queue on this CU (the vector-memory path returns in order)
-    const bool stager = wave < ENG_STAGERS;
-    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
-    if (stager) {
-        xraw = reinterpret_cast<const u32x4*>(a.x)[tid];
-        if (NORM) wraw = reinterpret_cast<const u32x4*>(a.rms_w)[tid];
-    }
+    // their x loads go out in front of everything the loader will queue on this CU (the vector-memory path returns in order)
+    const u32x4 xraw = reinterpret_cast<const u32x4*>(a.x)[tid];
+    u32x4 wraw = {0u, 0u, 0u, 0u};
+    if (NORM) wraw = reinterpret_cast<const u32x4*>(a.rms_w)[tid];
     asm volatile("s_barrier" ::: "memory");   // nobody waits for a vector load here
     if (wave == 0) ENG_STAMP(16);
     u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
     float* sx = reinterpret_cast<float*>(smem + L::SX);
     float* part = reinterpret_cast<float*>(smem + L::PART);
     float* tot = reinterpret_cast<float*>(smem + L::TOT);
-    {   // x chain: the staging of gemv_q4_body (stage_tail), one chunk per stager thread
+    {   // x chain: the staging of gemv_q4_body (stage_tail), one chunk per thread
         float ss = 1.f;
         if (NORM) {
-            if (stager) part[tid] = sumsq8(xraw, 0.f);
-            consumer_barrier(&flags[F_BAR0], lane, NC);
-            if (stager) ss = rms_scale_from_partials<KSL * 256>(part, KSL * 256, a.K);
+            part[tid] = sumsq8(xraw, 0.f);
+            consumer_barrier(&flags[F_BAR0], lane);
+            ss = rms_scale_from_partials<KSL * 256>(part, KSL * 256, a.K);
         }
-        if (stager) {
-            u32x4 v = xraw;
-            if (NORM) v = rms_apply8(v, wraw, ss);
-            const u32x4 pv = permute_x8(v);
-            const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
-            float cb = 0.f;
+        u32x4 v = xraw;
+        if (NORM) v = rms_apply8(v, wraw, ss);
+        const u32x4 pv = permute_x8(v);
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        float cb = 0.f;
 #pragma unroll
-            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
-            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum: the 32 inputs of one uint4 unit
-            const unsigned j = tid >> 2, d = tid & 3u;
-            xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
-            if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
-        }
-        consumer_barrier(&flags[F_BAR1], lane, NC);
+        for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+        cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum: the 32 inputs of one uint4 unit
+        const unsigned j = tid >> 2, d = tid & 3u;
+        xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+        if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
+        consumer_barrier(&flags[F_BAR1], lane);
     }
     if (wave == 0) ENG_STAMP(17);
     u32x4 X[KSL][4];
@@ -203,35 +203,34 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
         for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lane];
         corr[ks] = sx[ks * 64 + lane];
     }
-    // Work units: one (quad, matrix, column) = both k-slots of one column = 2 KiB of a ring slot; unit u = quad * 8 + matrix * 4 +
-    // column, dealt round-robin to the NC consumer waves (every wave holds all of x, so any wave can take any unit). A wave's
-    // units of one group of four are reduced together (the transposing reduce of gemv_q4.h leaves unit r's total in DPP row r).
-    const int nunits = nq * 8;
+    // wave w owns (column w / 2, matrix w % 2) of every quad: its addresses inside a slot and inside the side data are constants
+    const int col = wave >> 1, mat = wave & 1;
+    const unsigned char* wbase = smem + L::RING + (unsigned)((mat * 4 + col) * KSL) * 1024u + lane * 16u;
+    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)col * (16u * KSL) + (lane >> 2)) * 2u;
+    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)col * (2u * KSL) + (lane >> 5)) * 4u;
     const unsigned zsh = ((lane >> 2) & 7u) * 4u;      // nibble of this lane's group in its zeros word (16 groups per k-slot)
-    for (int u0 = wave; u0 < nunits; u0 += 4 * NC) {
+    unsigned known = 0;                                // fills this wave has seen landed: the flag is read again only past it
+
+    for (int g4 = 0; g4 * 4 < nq; g4++) {
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int u = u0 + r * NC;
-            if (u < nunits) {
-                const int i = u >> 3, mat = (u >> 2) & 1, col = u & 3;
-                lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u);
-                if (wave == 0 && r == 0) ENG_STAMP(18 + (u0 / (4 * NC)));
-                const unsigned char* sl = smem + L::RING + (unsigned)(i % ENG_RING) * L::SLOT + (unsigned)((mat * 4 + col) * KSL) * 1024u + lane * 16u;
-                const unsigned char* side_s = smem + L::SIDE_S + mat * L::SIDE_S_BYTES;
-                const unsigned char* side_z = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES;
+            const int i = g4 * 4 + r;
+            if (i < nq) {
+                if (known <= (unsigned)i) known = lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u);
+                if (wave == 0) ENG_STAMP(18 + i);
+                const unsigned char* sl = wbase + (unsigned)(i % ENG_RING) * L::SLOT;
                 u32x4 W[KSL];
                 unsigned zw[KSL];
                 uint16_t sc[KSL];
 #pragma unroll
-                for (int ks = 0; ks < KSL; ks++) {
-                    const unsigned grp = (unsigned)ks * 16u + (lane >> 2);          // quantisation group of unit ks * 64 + lane
+                for (int ks = 0; ks < KSL; ks++) {     // group of unit ks * 64 + lane = ks * 16 + lane / 4
                     W[ks] = *reinterpret_cast<const u32x4*>(sl + ks * 1024);
-                    sc[ks] = *reinterpret_cast<const uint16_t*>(side_s + ((unsigned)(i * 4 + col) * (16u * KSL) + grp) * 2u);
-                    zw[ks] = *reinterpret_cast<const unsigned*>(side_z + ((unsigned)(i * 4 + col) * (2u * KSL) + (grp >> 3)) * 4u);
+                    sc[ks] = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (128u * KSL) + ks * 32);
+                    zw[ks] = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (32u * KSL) + ks * 8);
                 }
-                // the ring slot is free once all 8 of its units have been read (LDS order: the bump follows the reads)
-                lds_bump(&flags[F_CONS0 + i % ENG_RING], lane);
+                // the slot is free once every consumer's reads have been executed (LDS order: the bump follows them)
+                lds_bump(&flags[F_CONSUMED], lane);
                 float c = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KSL; ks++) {
@@ -252,18 +251,18 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
                     c = __builtin_fmaf(h2f(sc[ks]), t, c);
                 }
                 cs[r] = c;
+                if (STAMPS && wave == 0) { asm volatile("" : "+v"(c)); ENG_STAMP(31 + i); }
             }
         }
-        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit u0 + r * NC
-        const int ur = u0 + (int)(lane >> 4) * NC;
-        if ((lane & 15u) == 0 && ur < nunits) tot[ur] = total;
-        if (wave == 0) { ENG_STAMP(31 + (u0 / (4 * NC))); }
+        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: the column of slot g4 * 4 + r
+        const int row = lane >> 4;
+        if ((lane & 15u) == 0 && g4 * 4 + row < nq) tot[(g4 * 4 + row) * 8 + wave] = total;
     }
-    consumer_barrier(&flags[F_BAR2], lane, NC);
+    consumer_barrier(&flags[F_BAR2], lane);
     if (wave == 0) ENG_STAMP(44);
     if ((int)tid < nq * 4) {
         const int i = tid >> 2, c = tid & 3;
-        const float g = tot[i * 8 + c], u = tot[i * 8 + 4 + c];
+        const float g = tot[i * 8 + c * 2], u = tot[i * 8 + c * 2 + 1];
         float val = g;
         val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
         val *= u;                                       // :272
@@ -271,43 +270,48 @@ __global__ void __launch_bounds__((NC + 1) * 64) ffn_engine_kernel(const GemvArg
     }
     if (wave == 0) ENG_STAMP(45);
 }
+#undef ENG_STAMP
 
-// the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU.
-// g_engine = lag (1..3) + 4 * consumer-wave choice (0: 8, 1: 15, 2: 12)
+// the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
 bool ffn_engine_covers(const GemvArgs& a) {
-    return g_engine >= 1 && (g_engine & 3) != 0 && (g_engine >> 2) <= 2 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+    return g_engine >= 1 && g_engine <= 3 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
            divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count();
 }
 
-template <int KSL, bool NORM, int LAG, int NC>
+template <int KSL, bool NORM, int LAG, bool STAMPS>
 static int launch_engine(const GemvArgs& a) {
     static bool opted = false;
+    constexpr size_t smem = EngLds<KSL>::BYTES;
     if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EngLds<KSL>::BYTES));
+        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         opted = true;
     }
     const unsigned nquads = (unsigned)a.N >> 2, nb = (unsigned)cu_count();
-    Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, NC>), dim3(nb), dim3((NC + 1) * 64), EngLds<KSL>::BYTES, a, nquads / nb, nquads % nb);
+    Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, STAMPS>), dim3(nb), dim3((ENG_CONSUMERS + 1) * 64), smem, a, nquads / nb, nquads % nb);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
 
-template <int NC>
-static int launch_engine_nc(const GemvArgs& a) {
-    const bool norm = a.rms_w != nullptr;
-    switch (g_engine & 3) {
-        case 1: return norm ? launch_engine<2, true, 1, NC>(a) : launch_engine<2, false, 1, NC>(a);
-        case 2: return norm ? launch_engine<2, true, 2, NC>(a) : launch_engine<2, false, 2, NC>(a);
-        default: return norm ? launch_engine<2, true, 3, NC>(a) : launch_engine<2, false, 3, NC>(a);
+template <bool NORM, bool STAMPS>
+static int launch_engine_lag(const GemvArgs& a) {
+    switch (g_engine) {
+        case 1: return launch_engine<2, NORM, 1, STAMPS>(a);
+        case 2: return launch_engine<2, NORM, 2, STAMPS>(a);
+        default: return launch_engine<2, NORM, 3, STAMPS>(a);
     }
 }
 
 int launch_ffn_engine(const GemvArgs& a) {
-    switch (g_engine >> 2) {
-        case 0: return launch_engine_nc<8>(a);
-        case 1: return launch_engine_nc<15>(a);
-        default: return launch_engine_nc<12>(a);
-    }
+    const bool norm = a.rms_w != nullptr;
+    if (a.dbg) return norm ? launch_engine_lag<true, true>(a) : launch_engine_lag<false, true>(a);
+    return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);
 }
+
+#else    // the shipped library: no engine
+
+bool ffn_engine_covers(const GemvArgs&) { return false; }
+int launch_ffn_engine(const GemvArgs&) { return Q4_ERR_UNSUPPORTED_SIZE; }
+
+#endif
 
 }  // namespace q4

@@ -18,6 +18,8 @@ int g_fusion = 3;
 int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
+static int g_rearm_after = 0;          // > 0: sequences left at fusion level 1 before level 3 is tried again (after a timed-out hand-off)
+static int g_rearm_backoff = 16;       // sequences to sit out after the next time-out: doubles every time, so a box that keeps stalling settles at level 1
 static int g_handoff_timeouts = 0;     // timed-out in-launch waits seen by q4_handoff_status since the library was loaded
 char g_last_error[512] = "";
 hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -43,6 +45,7 @@ static std::map<const Transformer*, Slabs> g_slabs;
 static std::map<const RunState*, const float2*> g_rope_by_state;
 static std::map<const RunState*, unsigned*> g_sync_by_state;
 static std::map<const RunState*, size_t> g_sync_words;   // words per model; word 0 is the sticky error flag
+static std::map<const RunState*, size_t> g_att_bytes;    // bytes of RunState::att (the split-context records live there)
 const float2* rope_table_of(const RunState* s) {
     auto it = g_rope_by_state.find(s);
     return it == g_rope_by_state.end() ? nullptr : it->second;
@@ -50,6 +53,29 @@ const float2* rope_table_of(const RunState* s) {
 static unsigned* sync_words_of(const RunState* s) {
     auto it = g_sync_by_state.find(s);
     return it == g_sync_by_state.end() ? nullptr : it->second;
+}
+// Hand-off state between sequences / launch-sequence changes / after a time-out. The EPOCH word is never rewound: the tag of a
+// launch is the epoch as it finds it, and the tagged words that outlive a launch -- the attention granules and the split-context
+// records in RunState::att -- validate themselves by tag alone, so a tag must never repeat during the life of the model (a second
+// sequence that reached the same (position, layer) used to re-create the first one's tag and could merge its stale records).
+// Cleared: arrival counters and granules, and the error word when asked. Past 2^31 launches (days of decoding) the epoch does
+// start over, together with every buffer that holds tags.
+static int clear_handoff_state(const RunState* s, bool error_too) {
+    unsigned* sync = sync_words_of(s);
+    auto it = g_sync_words.find(s);
+    if (!sync || it == g_sync_words.end() || it->second <= SYNC_EPOCH + 1) return Q4_OK;
+    if (error_too) Q4_HIP(hipMemsetAsync(sync + SYNC_ERROR, 0, sizeof(unsigned), g_stream));
+    Q4_HIP(hipMemsetAsync(sync + SYNC_EPOCH + 1, 0, (it->second - SYNC_EPOCH - 1) * sizeof(unsigned), g_stream));
+    Q4_HIP(hipStreamSynchronize(g_stream));
+    unsigned epoch = 0;
+    Q4_HIP(hipMemcpy(&epoch, sync + SYNC_EPOCH, sizeof(epoch), hipMemcpyDeviceToHost));
+    if (epoch >= 0x80000000u) {
+        Q4_HIP(hipMemsetAsync(sync + SYNC_EPOCH, 0, sizeof(unsigned), g_stream));
+        auto ab = g_att_bytes.find(s);
+        if (ab != g_att_bytes.end() && s->att) Q4_HIP(hipMemsetAsync(s->att, 0, ab->second, g_stream));
+        Q4_HIP(hipStreamSynchronize(g_stream));
+    }
+    return Q4_OK;
 }
 
 // graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
@@ -149,14 +175,10 @@ int q4_memset(void* dst, int value, size_t bytes) {
 // level 1 in round 2 and removed in round 3: the value selects level 1.
 void q4_set_fusion(int level) {
     g_fusion = level <= 0 ? 0 : level >= 3 ? 3 : 1;
+    g_rearm_after = 0;          // an explicit choice ends the probation after a time-out (and is the documented way to re-arm at once)
     q4_reset_graphs();
-    for (auto& kv : g_sync_by_state) {     // no stale epoch / granules across a change of launch sequence
-        auto it = g_sync_words.find(kv.first);
-        if (it != g_sync_words.end() && it->second > SYNC_EPOCH && g_stream) {
-            hipMemsetAsync(kv.second + SYNC_EPOCH, 0, (it->second - SYNC_EPOCH) * sizeof(unsigned), g_stream);
-            hipStreamSynchronize(g_stream);
-        }
-    }
+    if (g_stream)
+        for (auto& kv : g_sync_by_state) (void)clear_handoff_state(kv.first, false);   // no stale counters / granules across a change of launch sequence
 }
 int q4_get_fusion(void) { return g_fusion; }
 void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
@@ -374,6 +396,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         g_slabs[t] = slabs;
         g_sync_by_state[&t->state] = slabs.sync;
         g_sync_words[&t->state] = sync_words;
+        g_att_bytes[&t->state] = att_buffer_bytes(p);
     } else {
         (void)hipGetLastError();    // no hand-off words: the network runs its five-launch sequence
     }
@@ -395,6 +418,7 @@ void q4_free_transformer(Transformer* t) {                                      
         g_rope_by_state.erase(&t->state);
         g_sync_by_state.erase(&t->state);
         g_sync_words.erase(&t->state);
+        g_att_bytes.erase(&t->state);
         g_slabs.erase(it);
     }
     free(t->weights.layers);
@@ -694,11 +718,8 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
 // ---------------------------------------------------------------------------------------------------
 int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens) {
     Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
-    if (unsigned* sync = sync_words_of(s)) {     // hand-off words are zero between launches; also after a failed one
-        auto it = g_sync_words.find(s);
-        if (it != g_sync_words.end() && it->second > SYNC_EPOCH)   // the error word [0] stays until q4_handoff_status reads it
-            Q4_HIP(hipMemsetAsync(sync + SYNC_EPOCH, 0, (it->second - SYNC_EPOCH) * sizeof(unsigned), g_stream));
-    }
+    if (g_rearm_after > 0 && --g_rearm_after == 0 && g_fusion == 1) { g_fusion = 3; q4_reset_graphs(); }   // probation over
+    Q4_TRY(clear_handoff_state(s, false));     // counters and granules; the error word [0] stays until q4_handoff_status reads it
     Q4_HIP(hipStreamSynchronize(g_stream));
     s->shared_data->pos = 0;                                                       // :462
     if (prompt_tokens && num_prompt_tokens > 0)
@@ -722,8 +743,10 @@ int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p
 }
 // The in-launch hand-offs of fusion level 3 (attention -> o-proj, layer_attn.h) spin for a bounded time; a spin that ran out
 // sets the model's error word: everything computed since is invalid. Synchronises the stream and reports it ONCE: the word,
-// the epoch, the counters and the granules are cleared, and the library drops to fusion level 1 (no in-launch waits) for
-// the rest of the process, so the caller can simply redo the sequence -- the token loops of this library do exactly that.
+// the counters and the granules are cleared (the epoch keeps counting: tags never repeat), and the library drops to fusion
+// level 1 (no in-launch waits), so the caller can simply redo the sequence -- the token loops of this library do exactly that.
+// Level 3 comes back by itself after 16 sequences (q4_reset_sequence counts them; 32, 64, ... after further time-outs) or at
+// once with q4_set_fusion(3).
 int q4_handoff_status(const RunState* s) {
     Q4_HIP(hipStreamSynchronize(g_stream));
     unsigned* sync = sync_words_of(s);
@@ -732,11 +755,15 @@ int q4_handoff_status(const RunState* s) {
     unsigned flag = 0;
     Q4_HIP(hipMemcpy(&flag, sync + SYNC_ERROR, sizeof(flag), hipMemcpyDeviceToHost));
     if (flag) {
-        Q4_HIP(hipMemsetAsync(sync, 0, it->second * sizeof(unsigned), g_stream));
-        Q4_HIP(hipStreamSynchronize(g_stream));
+        Q4_TRY(clear_handoff_state(s, true));
         g_handoff_timeouts++;
-        if (g_fusion >= 3) { g_fusion = 1; q4_reset_graphs(); }
-        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 3); state cleared, continuing at fusion level 1");
+        if (g_fusion >= 3) {    // one transient stall (a profiler attaching, a co-tenant) must not cost every later sequence its 3 %
+            g_fusion = 1;
+            g_rearm_after = g_rearm_backoff;
+            if (g_rearm_backoff < (1 << 20)) g_rearm_backoff *= 2;
+            q4_reset_graphs();
+        }
+        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 3); state cleared, continuing at fusion level 1 for the next %d sequences", g_rearm_after);
         if (!g_quiet) fprintf(stderr, "llama2_q4: %s\n", g_last_error);
         return Q4_ERR_HIP;
     }
