@@ -167,11 +167,15 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     if (STAMPS && a.dbg) ts[3] = __builtin_readcyclecounter();
 
     // ---- softmax statistics (gpu_kernels.h:373-396) ------------------------------------------------
+    // launches whose sequence-length bin exceeds 8192 run softmax_kernel_no_smem in the reference (llama2_q4.cu:276-279): the
+    // exponential goes back to the fp16 `att` buffer (gpu_kernels.h:432) while the fp32 value is summed (:433), and the
+    // normalisation divides the ROUNDED exponential (:445)
+    const bool no_smem = !FUSED && a.lds_scores > 8192;
     const float m = row16_max(red_max[lane & 15]);
     float sum = 0.f;
     for (int t = tid; t < size; t += NW * 64) {
         const float e = expf(sc[t] - m);
-        sc[t] = e;
+        sc[t] = no_smem ? round_h(e) : e;
         sum += e;
     }
     sum = wave_sum(sum);

@@ -594,7 +594,37 @@ int build_sampler(Sampler* sampler, int vocab_size, float temperature, float top
     Q4_HIP(hipMalloc((void**)&sampler->indices, vocab_size * sizeof(int)));        // sampler.h:22
     return Q4_OK;
 }
+// Coins of the sampled steps that run inside captured graphs: the xorshift stream stays on the host (sampler.h:31-40), the values
+// of the steps a replay covers are copied to a device ring indexed by position just before the replay (one small async copy per
+// replay), and topp_sample_kernel reads coins[position] -- so the launch needs no per-step argument and sampled steps go out
+// eight per replay like greedy ones. (The Sampler struct is the reference's: the ring lives beside it.)
+struct CoinRing { float* host; float* dev; int cap; };
+static std::map<const Sampler*, CoinRing> g_coin_rings;
+static const Sampler* g_graph_sampler = nullptr;     // what the captured sampled graphs have baked in
+static float g_graph_temperature = 0.f, g_graph_topp = 0.f;
+static const float* g_graph_coins = nullptr;
+static int coin_ring_for(const Sampler* sampler, int positions, CoinRing** out) {
+    CoinRing& r = g_coin_rings[sampler];
+    if (r.cap < positions) {
+        if (r.host) hipHostFree(r.host);
+        if (r.dev) hipFree(r.dev);
+        r = CoinRing{nullptr, nullptr, 0};
+        Q4_HIP(hipHostMalloc((void**)&r.host, (size_t)positions * sizeof(float), hipHostMallocDefault));
+        Q4_HIP(hipMalloc((void**)&r.dev, (size_t)positions * sizeof(float)));
+        r.cap = positions;
+    }
+    *out = &r;
+    return Q4_OK;
+}
 void destroy_sampler(Sampler* sampler) {
+    auto cr = g_coin_rings.find(sampler);
+    if (cr != g_coin_rings.end()) {
+        if (g_graph_sampler == sampler) { q4_reset_graphs(); g_graph_sampler = nullptr; g_graph_coins = nullptr; }
+        if (g_stream) hipStreamSynchronize(g_stream);
+        if (cr->second.host) hipHostFree(cr->second.host);
+        if (cr->second.dev) hipFree(cr->second.dev);
+        g_coin_rings.erase(cr);
+    }
     if (sampler->indices) hipFree(sampler->indices);
     if (sampler->tempStorage_sort) hipFree(sampler->tempStorage_sort);
     if (sampler->tempStorage_scan) hipFree(sampler->tempStorage_scan);
@@ -619,7 +649,9 @@ void q4_sampler_delete(Sampler* s) {
     free(s);
 }
 
-__attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin);   // q4_sampling.hip
+__attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin, const float* coins, q4_half* x_next,
+                                                                const q4_half* table, int dim);   // q4_sampling.hip
+__attribute__((visibility("hidden"))) int q4_sample_topp_prepare(Sampler* sampler);
 
 static bool sampler_is_greedy(const Sampler* sampler, int gen_token) {
     return sampler->temperature == 0.0f || !gen_token;                             // sampler.h:47
@@ -633,7 +665,7 @@ static int sample_impl(Sampler* sampler, RunState* s, int gen_token, bool launch
             return q4_argmax(s->logits, sampler->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
         return Q4_OK;
     }
-    return q4_sample_topp_device(sampler, s, coin);
+    return q4_sample_topp_device(sampler, s, coin, nullptr, nullptr, nullptr, 0);
 }
 int q4_sample(Sampler* sampler, RunState* s, int gen_token) { return sample_impl(sampler, s, gen_token, true); }
 
@@ -672,13 +704,26 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
     const bool greedy = sampler_is_greedy(pSampler, gen_token);
     int seq_len_bin;
     const int graphIndex = graph_bin(seq_len, p, &seq_len_bin);
-    if (nsteps != 1 && (nsteps != g_multi_steps || !greedy || !g_use_graphs)) return Q4_ERR_ARG;
+    if (nsteps != 1 && (nsteps != g_multi_steps || !g_use_graphs)) return Q4_ERR_ARG;
+    if (pos < 0 || pos + nsteps > p->seq_len) return Q4_ERR_ARG;
 
     if (g_use_graphs) {
         if (g_graph_owner != (const void*)s) { q4_reset_graphs(); g_graph_owner = s; }
         // Unlike the reference, the greedy sampler kernel and the fp32 logits copy are part of the captured
         // graph (one launch per token instead of up to three); the variant index keeps them apart.
         const int variant = (gen_token ? 1 : 0) | (copyLogits ? 2 : 0) | (greedy ? 0 : 4) | (nsteps > 1 ? 8 : 0);
+        CoinRing* ring = nullptr;
+        if (!greedy) {     // the sampling kernel is part of the graph: its temperature, top-p, scratch and coin ring are baked in
+            Q4_TRY(coin_ring_for(pSampler, p->seq_len, &ring));
+            Q4_TRY(q4_sample_topp_prepare(pSampler));     // scratch + LDS opt-in: not capturable
+            if (g_graph_sampler != pSampler || g_graph_temperature != pSampler->temperature || g_graph_topp != pSampler->topp ||
+                g_graph_coins != ring->dev) {
+                for (int i = 0; i < Q4_MAX_GRAPHS; i++)
+                    for (int v = 4; v < 16; v++)
+                        if ((v & 4) && g_captured[i][v]) { hipGraphExecDestroy(g_graphs[i][v]); g_captured[i][v] = false; }
+                g_graph_sampler = pSampler; g_graph_temperature = pSampler->temperature; g_graph_topp = pSampler->topp; g_graph_coins = ring->dev;
+            }
+        }
         if (!g_captured[graphIndex][variant]) {                                    // :362-371
             hipGraph_t graph = nullptr;
             Q4_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
@@ -686,7 +731,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             // generated tokens, several steps per replay: step i + 1 takes the token step i writes -- its sampler launch leaves the
             // embedding row in s->x and the copy_embedding launch of step i + 1 is left out (the fused sequence only: level 0 is
             // the reference's 1:1 launch list)
-            const bool feed = greedy && gen_token && nsteps > 1 && g_fusion >= 1;
+            const bool feed = gen_token && nsteps > 1 && g_fusion >= 1;
             for (int i = 0; i < nsteps && !rc; i++) {
                 rc = run_network(s->pos, p, s, w, seq_len_bin, feed && i > 0);
                 if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
@@ -696,6 +741,8 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
                                                 s->x, w->token_embedding_table, p->dim);
                     else
                         rc = q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token);
+                } else if (!rc) {   // sampler.h:51-81 inside the graph: the coin comes from the ring, by position
+                    rc = q4_sample_topp_device(pSampler, s, 0.f, ring->dev, feed && i + 1 < nsteps ? s->x : nullptr, w->token_embedding_table, p->dim);
                 }
             }
             hipError_t e = hipStreamEndCapture(g_stream, &graph);
@@ -705,10 +752,14 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             Q4_HIP(hipGraphDestroy(graph));
             g_captured[graphIndex][variant] = true;
         }
-        Q4_HIP(hipGraphLaunch(g_graphs[graphIndex][variant], g_stream));          // :372
-        int rc = Q4_OK;
-        for (int i = 0; i < nsteps && !rc; i++) rc = sample_impl(pSampler, s, gen_token, false);   // :384 (argmax is in the graph;
-        return rc;                                                                 //  the RNG still advances once per step, P8)
+        // one coin per step, drawn whether the step samples or not (sampler.h:45, P8); the sampled steps' coins go to the ring
+        for (int i = 0; i < nsteps; i++) {
+            const float coin = random_f32(&pSampler->rng_state);
+            if (ring) ring->host[pos + i] = coin;
+        }
+        if (ring) Q4_HIP(hipMemcpyAsync(ring->dev + pos, ring->host + pos, (size_t)nsteps * sizeof(float), hipMemcpyHostToDevice, g_stream));
+        Q4_HIP(hipGraphLaunch(g_graphs[graphIndex][variant], g_stream));          // :372 (:384: the sampler launch is in the graph)
+        return Q4_OK;
     }
     Q4_TRY(q4_run_llama_network(s->pos, p, s, w, seq_len));                       // :374
     if (copyLogits) Q4_TRY(q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos));   // :377-382
@@ -736,7 +787,7 @@ int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p
     if (k <= 1 || !g_use_graphs || pos + k > steps || pos + k > p->seq_len) return 1;
     const bool gen0 = pos >= num_prompt_tokens - 1, gen1 = pos + k - 1 >= num_prompt_tokens - 1;
     if (gen0 != gen1) return 1;
-    if (gen0 && sampler->temperature != 0.0f) return 1;
+    (void)sampler;     // sampled steps take their coins from a device ring by position: they go out k per replay too
     int b0, b1;
     if (graph_bin(pos + 1, p, &b0) != graph_bin(pos + k, p, &b1)) return 1;
     return k;

@@ -278,14 +278,21 @@ __device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot
     __syncthreads();
 }
 
+// coins != nullptr (the step is part of a captured graph): the coin of this step is coins[position] -- the host draws the
+// xorshift stream (sampler.h:31-40) ahead of the replay and leaves the values in a pinned ring, so the launch carries no
+// per-step argument -- else `coin`. x_next != nullptr (several steps per replay): the sampled token's embedding row becomes the
+// next step's residual stream right here, like argmax_kernel does for greedy steps.
 __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int n, float temperature, int do_sort,
-                                                          float threshold, int* indices, uint16_t* k0, int* v0,
+                                                          float coin, const float* coins, float topp, int* indices, uint16_t* k0, int* v0,
                                                           uint16_t* k1, int* v1, int* result, volatile int* pPos,
-                                                          int* pPosGpu) {
+                                                          int* pPosGpu, q4_half* x_next, const q4_half* table, int dim) {
     extern __shared__ __attribute__((aligned(16))) unsigned dyn[];   // [32768] sort buffer (on-chip path) + [4096] counters
     __shared__ float red[16];
     __shared__ unsigned wtot[16];
     __shared__ int hit;
+    __shared__ int s_token;
+    if (coins != nullptr) coin = coins[*pPosGpu];            // (requested first: a PCIe read that returns under the softmax)
+    const float threshold = do_sort ? coin * topp : coin;    // sampler.h:57-59,69
     const bool onchip = n <= SMP_T * SMP_E;
     unsigned* buf = dyn;
     unsigned* cnt = onchip ? dyn + SMP_T * SMP_E : dyn;
@@ -332,6 +339,13 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
         scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
         if (tid == 0) token = v1[hit == 0x7fffffff ? n - 1 : hit];
     }
+    if (x_next != nullptr) {                                 // (uniform: a kernel argument)
+        if (tid == 0) s_token = token;
+        __syncthreads();
+        const int tk = s_token;
+        for (int u = tid; u < (dim >> 3); u += SMP_T)
+            reinterpret_cast<u32x4*>(x_next)[u] = reinterpret_cast<const u32x4*>(table + (size_t)tk * dim)[u];
+    }
     if (tid == 0) {
         int token_pos = *pPosGpu;                            // == *pPos (:579-580) without the PCIe read
         token_pos++;
@@ -344,27 +358,35 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin) {
+// scratch and LDS opt-in of the sampling launch: outside any stream capture (hipMalloc / hipFuncSetAttribute are not capturable)
+extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_prepare(Sampler* sampler) {
     const int n = sampler->vocab_size;
-    const int do_sort = !(sampler->topp <= 0 || sampler->topp >= 1);
-    const float threshold = do_sort ? coin * sampler->topp : coin;                   // sampler.h:57-59,69
-    if (sampler->temp_storage_bytes_sort == 0) {                                    // :62-66 (lazy scratch)
+    if (sampler->temp_storage_bytes_sort == 0) {                                    // sampler.h:62-66 (lazy scratch)
         const size_t bytes = 2 * ((size_t)n * sizeof(uint16_t) + 256) + 2 * ((size_t)n * sizeof(int) + 256);
         Q4_HIP(hipMalloc(&sampler->tempStorage_sort, bytes));
         sampler->temp_storage_bytes_sort = bytes;
     }
-    char* base = (char*)sampler->tempStorage_sort;
-    const size_t kb = ((size_t)n * sizeof(uint16_t) + 255) / 256 * 256, vb = ((size_t)n * sizeof(int) + 255) / 256 * 256;
-    uint16_t* k0 = (uint16_t*)base; uint16_t* k1 = (uint16_t*)(base + kb);
-    int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
-    const size_t smem = (n <= SMP_T * SMP_E ? (size_t)SMP_T * SMP_E * 4 : 0) + 256 * SMP_W * 4;
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
         lds_opt_in = true;
     }
-    Q4_LAUNCH(topp_sample_kernel, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, threshold,
-              sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos);   // :53-80
+    return Q4_OK;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin, const float* coins,
+                                                                           q4_half* x_next, const q4_half* table, int dim) {
+    const int n = sampler->vocab_size;
+    const int do_sort = !(sampler->topp <= 0 || sampler->topp >= 1);
+    if (x_next != nullptr && (dim & 7)) return Q4_ERR_UNSUPPORTED_SIZE;
+    if (coins == nullptr) { int rc = q4_sample_topp_prepare(sampler); if (rc) return rc; }   // (graph path: prepared before the capture)
+    char* base = (char*)sampler->tempStorage_sort;
+    const size_t kb = ((size_t)n * sizeof(uint16_t) + 255) / 256 * 256, vb = ((size_t)n * sizeof(int) + 255) / 256 * 256;
+    uint16_t* k0 = (uint16_t*)base; uint16_t* k1 = (uint16_t*)(base + kb);
+    int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
+    const size_t smem = (n <= SMP_T * SMP_E ? (size_t)SMP_T * SMP_E * 4 : 0) + 256 * SMP_W * 4;
+    Q4_LAUNCH(topp_sample_kernel, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, coin, coins, sampler->topp,
+              sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, x_next, table, dim);   // :53-80
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }

@@ -43,6 +43,10 @@ GEOMETRIES = {
     "head128_k5120": (5120, 1408, 1, 40, 40, 512, 300, 10000.0),
     "head128_gqa": (2560, 3584, 2, 20, 4, 512, 700, 1000000.0),   # grouped-query (kv_mul 5) with a fused attention + o-proj form
     "head64_long": (512, 1408, 2, 8, 4, 512, 1300, 10000.0),     # head 64, grouped-query, context past the split threshold
+    # seq_len 16384: the graph bins 4096 / 8192 and the last bin (= seq_len, llama2_q4.cu:360), where the reference's attention
+    # switches to softmax_kernel_no_smem (> 8192, :276-279); head 64 and head 128, grouped-query
+    "long16k": (512, 1408, 2, 8, 2, 512, 16384, 10000.0),
+    "long16k_h128": (512, 1408, 2, 4, 2, 512, 16384, 1000000.0),
     # the other head sizes / K widths of the attention -> o-proj launch: TinyLlama-1.1B's shape (head 64, GQA 8:1, K = 2048 in
     # ONE k-slot), a head-256 model, and K = dim = 8192 in four k-slots with 70B-style GQA
     "tinyllama": (2048, 5632, 2, 32, 4, 512, 1100, 10000.0),

@@ -78,6 +78,10 @@ def lib():
     L.orc_rope.argtypes = [u16p, u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
     L.orc_attention.restype = None
     L.orc_attention.argtypes = [u16p, u16p, u16p, u16p, u16p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_attention_bin.restype = None
+    L.orc_attention_bin.argtypes = [u16p, u16p, u16p, u16p, u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_seq_len_bin.restype = C.c_int
+    L.orc_seq_len_bin.argtypes = [C.c_int, C.c_int]
     L.orc_argmax.restype = C.c_int
     L.orc_argmax.argtypes = [u16p, C.c_int]
     L.orc_compute_perplexity.restype = C.c_float
@@ -161,11 +165,12 @@ def rope(q, k, num_heads, num_kv_heads, head_size, pos, theta):
     return q, k
 
 
-def attention(q, kc, vc, num_heads, head_size, kv_mul, pos):
+def attention(q, kc, vc, num_heads, head_size, kv_mul, pos, max_seq_len=0):
+    """max_seq_len = the launch's sequence-length bin: above 8192 the reference runs softmax_kernel_no_smem (llama2_q4.cu:276-279)."""
     out = np.zeros(num_heads * head_size, dtype=np.float16)
     att = np.zeros(num_heads * (pos + 1), dtype=np.float16)
-    lib().orc_attention(f16_bits(out), f16_bits(q), f16_bits(kc), f16_bits(vc), f16_bits(att),
-                        num_heads, head_size, kv_mul, pos)
+    lib().orc_attention_bin(f16_bits(out), f16_bits(q), f16_bits(kc), f16_bits(vc), f16_bits(att),
+                            num_heads, head_size, kv_mul, pos, max_seq_len)
     return out, att.reshape(num_heads, pos + 1)
 
 

@@ -312,10 +312,12 @@ void orc_rope(f16 *sq, f16 *sk, int num_heads, int num_kv_heads, int head_size, 
 }
 
 /* ---- a9-a11: MultiHeadAttention, llama2_q4.cu:267-284 ------------------------
- * mat_vec_kernel_simple gpu_kernels.h:142-168, softmax_kernel :357-401, vec_mat_kernel :279-329.
- * kc/vc point at this layer's cache (key_cache + loff). att row stride is pos+1 (P4). */
-void orc_attention(f16 *out, const f16 *q, const f16 *kc, const f16 *vc, f16 *att,
-                   int num_heads, int head_size, int kv_mul, int pos) {
+ * mat_vec_kernel_simple gpu_kernels.h:142-168, softmax_kernel :357-401 (max_seq_len <= MAX_SEQ_LEN_SMEM_KERNEL = 8192) or
+ * softmax_kernel_no_smem :403-446 (above: llama2_q4.cu:276-279 -- max_seq_len is the graph's sequence-length bin), vec_mat_kernel
+ * :279-329. kc/vc point at this layer's cache (key_cache + loff). att row stride is pos+1 (P4). */
+#define ORC_MAX_SEQ_LEN_SMEM_KERNEL 8192                                        /* common.h */
+void orc_attention_bin(f16 *out, const f16 *q, const f16 *kc, const f16 *vc, f16 *att,
+                       int num_heads, int head_size, int kv_mul, int pos, int max_seq_len) {
     orc_init();
     int dim = head_size * num_heads;
     int kv_dim = dim / kv_mul;
@@ -355,7 +357,13 @@ void orc_attention(f16 *out, const f16 *q, const f16 *kc, const f16 *vc, f16 *at
             part[tid] = sum;
         }
         float sum = block_sum1024(part);
-        for (int t = 0; t < size; t++) a[t] = f2h(f[t] / sum);               /* :400 */
+        if (max_seq_len <= ORC_MAX_SEQ_LEN_SMEM_KERNEL) {
+            for (int t = 0; t < size; t++) a[t] = f2h(f[t] / sum);           /* :400 */
+        } else {
+            /* softmax_kernel_no_smem: the exponential is stored to `arr` as fp16 (:432) while the fp32 value is summed (:433);
+               the normalisation divides the ROUNDED exponential (:445) */
+            for (int t = 0; t < size; t++) a[t] = f2h(h2f(f2h(f[t])) / sum);
+        }
         free(f);
         /* att . V : lane = k index mod 32, sequential over 32-chunks, then warp sum (:304-325) */
         for (int n = 0; n < head_size; n++) {
@@ -369,6 +377,21 @@ void orc_attention(f16 *out, const f16 *q, const f16 *kc, const f16 *vc, f16 *at
             out[(size_t)h * head_size + n] = f2h(warp_sum32(lane));
         }
     }
+}
+
+void orc_attention(f16 *out, const f16 *q, const f16 *kc, const f16 *vc, f16 *att,
+                   int num_heads, int head_size, int kv_mul, int pos) {
+    orc_attention_bin(out, q, kc, vc, att, num_heads, head_size, kv_mul, pos, 0);
+}
+
+/* the sequence-length bin run_transformer launches run_llama_network with, llama2_q4.cu:354-360 */
+int orc_seq_len_bin(int pos, int model_seq_len) {
+    int seq_len = pos + 1;
+    int graphIndex, seq_len_bin = 128;
+    for (graphIndex = 0; graphIndex < 8 - 1; seq_len_bin *= 2, graphIndex++)  /* MAX_GRAPHS = 8, llama2_q4.cu:342 */
+        if (seq_len <= seq_len_bin) break;
+    if ((seq_len > seq_len_bin) || (graphIndex == 8 - 1)) seq_len_bin = model_seq_len;
+    return seq_len_bin;
 }
 
 /* ---- a13: argmax_kernel, gpu_kernels.h:448-493 (ties -> lowest index, a legal outcome) */
@@ -575,7 +598,8 @@ void orc_forward(OrcModel *m, int token, int pos) {
         orc_matmul_q4(m->key_cache, m->xb, L->k.weight, L->k.zeros, L->k.scales, dim, kv_dim, 0, loff, pos);
         orc_matmul_q4(m->value_cache, m->xb, L->v.weight, L->v.zeros, L->v.scales, dim, kv_dim, 0, loff, pos);
         orc_rope(m->q, m->key_cache + loff + (size_t)pos * kv_dim, p->n_heads, p->n_kv_heads, head_size, pos, p->rope_theta); /* :317 */
-        orc_attention(m->xb, m->q, m->key_cache + loff, m->value_cache + loff, m->att, p->n_heads, head_size, kv_mul, pos); /* :320 */
+        orc_attention_bin(m->xb, m->q, m->key_cache + loff, m->value_cache + loff, m->att, p->n_heads, head_size, kv_mul, pos,
+                          orc_seq_len_bin(pos, p->seq_len));                  /* :320, bin from run_transformer :354-360 */
         orc_matmul_q4(m->x, m->xb, L->o.weight, L->o.zeros, L->o.scales, dim, dim, 1, -1, 0);        /* :323 */
         orc_rmsnorm(m->xb, x, L->rms_ffn, dim);                               /* :326 */
         orc_ffn_matvec_silu(m->hb, m->xb, L->gate.weight, L->gate.zeros, L->gate.scales,

@@ -26,6 +26,7 @@ from llama_cu_awq_amd import synth
 pytestmark = pytest.mark.gpu
 
 PROMPT = [1, 2436, 385, 3686, 388, 1048, 22796, 118]      # "write an essay about GPUs", reference tokenizer
+PROMPT_SMALL = [1, 17, 300, 45, 9]                         # for the 512-entry vocabularies of the test-size models
 MODEL_DIR = os.environ.get("Q4_MODEL_DIR", "/tmp")
 
 
@@ -183,6 +184,53 @@ def _step_from_the_gpus_cache(q4, orc, path, target, observed, key):
 @pytest.mark.parametrize("target", [200, 400, 900, 1100, 2040])
 def test_config4_llama2_7b_long_context_through_captured_graphs(q4, orc, m7b, target, observed):
     _step_from_the_gpus_cache(q4, orc, m7b, target, observed, "config4_7b")
+
+
+@pytest.mark.parametrize("name", ["long16k", "long16k_h128"])
+@pytest.mark.parametrize("fusion", [3, 1])
+@pytest.mark.parametrize("target", [3000, 6000, 12000])
+def test_bins_above_2048_end_to_end(q4, orc, tmp_path_factory, observed, name, fusion, target):
+    """run_transformer's graph bins above 2048 (llama2_q4.cu:356-360): position 3000 -> bin 4096, 6000 -> bin 8192, 12000 -> the
+    LAST bin, which holds the model's seq_len (16384: the reference's attention then runs softmax_kernel_no_smem, :276-279, which
+    the restatement follows). The GPU decodes `target` positions through its captured graphs, the restatement takes the GPU's KV
+    cache and both run the next step. Head 64 and head 128, grouped-query; fusion level 3 (attention -> o-proj launch where the
+    shape has a form, split-context records as granules) and level 1 (stand-alone kernels)."""
+    L = q4.lib()
+    path = str(tmp_path_factory.getbasetemp() / (name + "_seed11.bin"))
+    if not os.path.exists(path):
+        synth.write_model(path, name, seed=11)
+    try:
+        L.q4_set_fusion(fusion)
+        t = q4.Transformer(path)
+        m = orc.Model(path)
+        assert orc.lib().orc_seq_len_bin(target, 16384) == {3000: 4096, 6000: 8192, 12000: 16384}[target]
+        toks, tps, timed, _ = t.generate_ids(PROMPT_SMALL, target)
+        assert timed == target - 1 and t.pos() == target
+        k, v = _kv_to_host(q4, t)
+        n = k.shape[0]
+        np.ctypeslib.as_array(m.L.orc_key_cache(m.h), shape=(n,))[:] = k
+        np.ctypeslib.as_array(m.L.orc_value_cache(m.h), shape=(n,))[:] = v
+        tok = int(t.token(target))
+        t.run_transformer(True)
+        q4.synchronize()
+        q4.check(L.q4_handoff_status(t.state))
+        got = t.logits()
+        ref = m.forward(tok, target)
+        e = _rel(got, ref)
+        observed["%s_fusion%d_pos%d" % (name, fusion, target)] = {"logits_max_rel_vs_restatement": e, "tok_s_to_target": tps}
+        assert e <= 1.2e-2, e          # two layers deep: measured <= 4e-3 (profiles/r04_parity_observed.json)
+        rk, rv = m.kv()
+        for layer in range(t.config.n_layers):
+            gk, gv = t.kv_row(layer, target)
+            assert _rel(gk, rk[layer, target]) <= 2.4e-2 and _rel(gv, rv[layer, target]) <= 1.2e-2, layer
+        r32 = ref.astype(np.float32)
+        top2 = np.sort(r32)[-2:]
+        if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):
+            assert int(t.token(target + 1)) == int(np.argmax(r32))
+        t.close()
+        m.close()
+    finally:
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
 
 
 def test_llama2_13b_inside_bin_256(q4, orc, observed):

@@ -351,10 +351,10 @@ def test_sampler_rng_after_an_early_stop_matches_one_draw_per_executed_step(q4, 
 
     L = q4.lib()
     seed = 1234
-    for stop in (5, 1, 7, 10):                                       # inside the first group, at its edge, inside the second
+    for stop, temperature in ((5, 0.0), (1, 0.0), (7, 0.0), (10, 0.0), (5, 0.7), (12, 0.7)):   # inside the first group, at its edge, inside the second; sampled groups too
         prompt = [1] + [5 + i for i in range(15)]
         prompt[stop] = 2
-        t = q4.Transformer(models["tiny"], seed=seed)
+        t = q4.Transformer(models["tiny"], seed=seed, temperature=temperature, topp=0.9)
         toks, tps, timed, secs = t.generate_ids(prompt, 40)
         assert timed + 1 == stop                                     # pos at the break (timed_tokens = pos - 1, :488)
         state = C.c_ulonglong(seed)

@@ -153,7 +153,7 @@ def test_attention_16k_context(q4, orc, rng, with_scratch):
     q = rng.standard_normal(dim).astype(np.float16)
     kc = (0.5 * rng.standard_normal(seq * kv_dim)).astype(np.float16)
     vc = rng.standard_normal(seq * kv_dim).astype(np.float16)
-    ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos)
+    ref, _ = orc.attention(q, kc, vc, heads, hs, kv_mul, pos, max_seq_len=seq)     # > 8192: the restated softmax_kernel_no_smem
     dq, dk, dv, do = q4.DevBuf(q), q4.DevBuf(kc), q4.DevBuf(vc), q4.DevBuf(nbytes=dim * 2)
     dpos = q4.DevBuf(np.array([pos], dtype=np.int32))
     att = q4.DevBuf(nbytes=heads * max(seq, dim) * 2 * 2) if with_scratch else None

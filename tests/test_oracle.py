@@ -148,3 +148,34 @@ def test_topp_restatement_against_plain_numpy(n, temperature, topp):
             assert pos == k, (coin, pos, k)
         agree += pos == k
     assert agree >= 0.7 * len(coins), agree
+
+
+def test_softmax_no_smem_restatement_and_the_bin_rule(orc, rng):
+    """Above 8192 positions per launch bin the reference's attention runs softmax_kernel_no_smem (llama2_q4.cu:276-279), whose
+    probabilities are half(float(half(exp)) / sum) (gpu_kernels.h:432,445) instead of half(exp / sum) (:400). The restated
+    probabilities must equal a plain numpy evaluation of exactly that formula on the restatement's own scores, differ from the
+    <= 8192 form in some entries, and the bin must follow run_transformer's rule (:354-360)."""
+    heads, hs, pos = 2, 64, 300
+    q = rng.standard_normal(heads * hs).astype(np.float16)
+    kc = rng.standard_normal((pos + 1) * heads * hs).astype(np.float16)
+    vc = rng.standard_normal((pos + 1) * heads * hs).astype(np.float16)
+    _, att_smem = orc.attention(q, kc, vc, heads, hs, 1, pos, max_seq_len=8192)
+    _, att_nosmem = orc.attention(q, kc, vc, heads, hs, 1, pos, max_seq_len=16384)
+    _, att_default = orc.attention(q, kc, vc, heads, hs, 1, pos)
+    assert np.array_equal(att_smem, att_default)
+    # recompute both from the fp16 scores: scores = half(alpha * q.k), the fp32 exp and sum as the kernels form them
+    Q = q.reshape(heads, hs).astype(np.float32)
+    K = kc.reshape(pos + 1, heads, hs).astype(np.float32)
+    sc = (np.einsum("hd,thd->ht", Q, K).astype(np.float32) * np.float32(1.0 / np.sqrt(hs))).astype(np.float16).astype(np.float32)
+    e = np.exp(sc - sc.max(axis=1, keepdims=True)).astype(np.float32)
+    s = e.sum(axis=1, keepdims=True, dtype=np.float32)
+    want_nosmem = (e.astype(np.float16).astype(np.float32) / s).astype(np.float16)
+    want_smem = (e / s).astype(np.float16)
+    from conftest import f16_ulp_diff
+    assert f16_ulp_diff(att_nosmem, want_nosmem).max() <= 1 and f16_ulp_diff(att_smem, want_smem).max() <= 1   # (sum order, expf)
+    assert (att_nosmem != att_smem).any()
+    L = orc.lib()
+    for pos_, seq, want in ((0, 2048, 128), (127, 2048, 128), (128, 2048, 256), (2047, 2048, 2048), (3000, 16384, 4096),
+                            (6000, 16384, 8192), (8191, 16384, 8192), (8192, 16384, 16384), (12000, 16384, 16384), (300, 320, 512),
+                            (3000, 4000, 4096), (9000, 32768, 32768)):
+        assert L.orc_seq_len_bin(pos_, seq) == want, (pos_, seq)

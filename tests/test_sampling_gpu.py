@@ -103,8 +103,35 @@ def test_sample_matches_restatement_at_production_vocab(q4, orc, big_vocab_model
     t.close()
 
 
+@pytest.mark.parametrize("temperature,topp", [(0.5, 0.6), (1.0, 0.9), (0.8, 1.0), (0.05, 0.9)])
+def test_sampled_steps_inside_the_graph_equal_the_stepwise_sampler(q4, model, temperature, topp):
+    """Sampled generation goes out eight steps per graph replay: topp_sample_kernel is part of the captured graph, reads its
+    coin from the device ring by position (the host draws the same xorshift stream, sampler.h:31-45) and leaves the sampled
+    token's embedding row for the next step. The token ring must equal the one of the reference-shaped loop -- one
+    run_transformer call per step (llama2_q4.cu:465-482), the next token read from the ring by copy_embedding -- across the bins
+    128 / 256, and a second sequence on the same graphs must continue the same coin stream. (The eager network is no yardstick
+    for SAMPLED tokens: it is launched with the exact context length instead of the bin, another fp32 grouping in the attention,
+    and a one-ulp logit moves a token whose prefix sum sits next to the coin.)"""
+    prompts = ([1, 5, 9], 300), ([1, 77, 3, 12], 150)
+    t = q4.Transformer(model, temperature=temperature, topp=topp, seed=4242)
+    grouped = [t.generate_ids(p, n)[0].copy() for p, n in prompts]      # the RNG stream continues into the second sequence
+    t.close()
+    t = q4.Transformer(model, temperature=temperature, topp=topp, seed=4242)
+    for (p, n), want in zip(prompts, grouped):
+        t.reset(p)
+        for pos in range(n):
+            t.run_transformer(pos >= len(p) - 1)
+            q4.synchronize()                                          # the reference order: the host reads SharedData::pos (:354)
+            if pos > 0 and t.token(pos) == 2:                         # generate() stops where the ring holds EOS (:473-477), after
+                break                                                 # launching that step: pos + 1 coins drawn either way
+        ring = np.array([t.token(i) for i in range(n + 1)], dtype=np.int32)
+        assert np.array_equal(ring[:len(want)], want), "first difference at %d" % int(np.nonzero(ring[:len(want)] != want)[0][0])
+    t.close()
+    assert len(set(grouped[0][4:].tolist())) > 8                      # it does sample (a constant ring would also be "equal")
+
+
 def test_generate_with_temperature_runs(q4, model):
-    """End to end: the CLI default (-t 0.5 -p 0.6) goes through the sampling kernels outside the captured graph."""
+    """End to end: the CLI default (-t 0.5 -p 0.6) goes through the sampling kernel inside the captured graph."""
     t = q4.Transformer(model, temperature=0.5, topp=0.6, seed=7)
     toks, tps, timed, _ = t.generate_ids([1, 5, 9], 24)
     assert timed == 23 and len(toks) >= 24 and (toks[3:24] < t.config.vocab_size).all() and (toks[3:24] >= 0).all()
