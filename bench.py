@@ -188,7 +188,7 @@ def main():
         # tracer). The line takes the LARGER of the two, so it never claims more than the committed profile supports; the
         # per-launch cost inside a hipGraph (kernel + boundary) is reported next to it.
         rocprof_us, rocprof_src = None, None
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             cpath = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s_%d_eager.csv" % (tag, args.model, ntok))
             if os.path.exists(cpath):
                 import csv
@@ -223,11 +223,21 @@ def main():
                                 "frac": round(kb[0][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
         traffic, traffic_src = None, None
         # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
-        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.model == "7b":
-                tj = json.load(open(tpath))
-                tj = tj.get("0", tj)
+                tj_all = json.load(open(tpath))
+                tj = tj_all.get("0", tj_all)
+                # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
+                prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": "gemv_q4_kernel<0,",
+                            "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": "gemv_f16_kernel<",
+                            kb[0][0]: "gemv_q4_kernel<2,"}
+                for nm_, pre_ in prefixes.items():
+                    ratios = [e_["traffic_over_algorithmic"] for k_, e_ in tj_all.get("%s_n%d" % (args.model, ntok), {}).items()
+                              if isinstance(e_, dict) and k_.replace("q4::", "").startswith(pre_) and "traffic_over_algorithmic" in e_]
+                    if ratios and nm_ in per_kernel:
+                        per_kernel[nm_]["traffic_over_algorithmic"] = round(max(ratios), 4)
+                        per_kernel[nm_]["traffic_source"] = "profiles/" + tname
                 if "traffic_bytes_per_launch" in tj:
                     traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % tname
                     break

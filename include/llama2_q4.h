@@ -129,7 +129,10 @@ typedef struct {
 /* ---- stream (replaces the file-scope `cudaStream_t stream`, llama2_q4.cu:207,700) ---------- */
 int q4_set_device(int device);
 int q4_stream_create(q4_stream_t* out);          /* cudaStreamCreate, llama2_q4.cu:700 */
-/* a stream restricted to the first n_cus compute units (hipExtStreamCreateWithCUMask): replicas side by side on one GPU */
+/* a stream restricted to the first n_cus compute units (hipExtStreamCreateWithCUMask): replicas side by side on one GPU.
+ * Fusion level 3 counts the waiting blocks of ITS launch against the CUs of ITS stream (the forward-progress guard): models that
+ * decode concurrently on one GPU at level 3 must use streams with DISJOINT CU masks (or level 1); two unmasked streams can fill
+ * every CU with each other's waiting blocks, which ends as bounded time-outs and a drop to level 1, never as a hang. */
 int q4_stream_create_masked(q4_stream_t* out, int n_cus);
 int q4_stream_destroy(q4_stream_t s);
 void q4_set_stream(q4_stream_t s);
@@ -212,7 +215,8 @@ int q4_run_transformer_at(int pos, int gen_token, const Config* p, RunState* s, 
                           int copyLogits, Sampler* pSampler);
 int q4_wait_pos(const RunState* s, int pos);
 /* Greedy steps need nothing from the host between tokens (the device keeps the position and feeds itself the ring), so a
- * token loop may queue Q4_MULTI_STEPS of them as ONE graph replay: q4_steps_that_fit says how many steps (Q4_MULTI_STEPS or
+ * token loop may queue Q4_MULTI_STEPS of them as ONE graph replay (sampled steps too: topp_sample_kernel is part of the graph and
+ * takes its coin from a device ring by position, filled by the host from the sampler's xorshift stream before the replay): q4_steps_that_fit says how many steps (Q4_MULTI_STEPS or
  * 1) may go out at `pos` -- same gen_token for the whole group, one sequence-length bin, within `steps` --, and
  * q4_run_transformer_steps queues them (nsteps = 1 is q4_run_transformer_at). generate() uses the pair. */
 enum { Q4_MULTI_STEPS = 8 };
@@ -225,8 +229,11 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * as ONE launch where the geometry has that form (heads of 64 / 128 / 256, multi-head or grouped-query) and every block of the
  * launch fits the stream's CUs at once: the o-proj blocks pull their weights while the heads work and take the heads' output
  * inside the launch (bounded waits, q4_handoff_status), 4 launches/layer. 2 selects 1 (round 2's QKV -> attention -> o-proj
- * launch was measured slower than level 1 and removed). Levels 1 and 3 run the same arithmetic (identical bits in the first
- * bin, the model's tolerance above it: the attention role groups its fp32 sums by 8 waves). Resets captured graphs. */
+ * launch was measured slower than level 1 and removed). Levels 1 and 3 run the same arithmetic with another fp32 grouping of an
+ * attention output's positions (below bin 512 the fused launch's attention role takes 16 positions per wave instruction of a
+ * 64-byte V slice, the stand-alone kernel 4; 8 waves instead of 16): logits agree within the model's tolerance in every bin, not
+ * bit for bit. After a timed-out hand-off the library runs level 1 for the next 16 sequences (32, 64, ... after further
+ * time-outs), then tries level 3 again; q4_set_fusion(3) re-arms it at once. Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */

@@ -5,7 +5,10 @@
 #include "q4_internal.h"
 using namespace q4;
 
-static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, const TransformerWeights* w) {
+// launch `kernel_id` on the i-th weight set of the ring (a different layer's weights every launch: > 256 MB in flight, past the
+// Infinity Cache). public_attention: id 6 through the C-ABI entry point (caller-owned `att`, two-launch merge) instead of the
+// network's internal launcher
+static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, const TransformerWeights* w, bool public_attention = false) {
     const int dim = p->dim, hidden = p->hidden_dim;
     const int head_size = dim / p->n_heads;
     const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
@@ -19,9 +22,12 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
                                         &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s), nullptr);
         case 4: return q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr);
         case 5: return q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f);
-        case 6: return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
-                                        p->n_heads / p->n_kv_heads, p->seq_len, s->pos, (float*)s->att,
-                                        att_buffer_bytes(p), nullptr);
+        case 6:
+            if (public_attention)
+                return q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads, head_size,
+                                               p->n_heads / p->n_kv_heads, p->seq_len, s->pos);
+            return launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size,
+                                    p->n_heads / p->n_kv_heads, p->seq_len, s->pos, (float*)s->att, att_buffer_bytes(p), nullptr);
         case 7: return q4_rmsnorm(s->xb, s->x, w->rms_final_weight, dim);
         case 8: return q4_argmax(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, 0);
         case 9: return q4_copy_embedding(s->x, w->token_embedding_table, dim, s->shared_data->tokens, s->pos);
@@ -62,30 +68,15 @@ extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, c
                                   double* min_us, double* max_us) {
     if (iters < 1 || !p || !s || !w) return -1.0;
     if (s->shared_data->pos >= p->seq_len) return -1.0;   // the kernels write the KV row of the device position: it must exist
-    const int dim = p->dim, hidden = p->hidden_dim;
-    const int head_size = dim / p->n_heads;
-    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    if (kernel_id < 0 || kernel_id > 6) return -1.0;       // ids 7-9 (tiny launches) are timed inside a graph only
     std::vector<hipEvent_t> ev(2 * iters);
     for (auto& e : ev)
         if (hipEventCreate(&e) != hipSuccess) return -1.0;
     int rc = 0;
     for (int i = 0; i < iters && !rc; i++) {
-        const PerLayerWeight* L = &w->layers[i % w->num_layers];   // ring: a different layer's weights every launch
-        const long long loff = (long long)(i % w->num_layers) * p->seq_len * kv_dim;
         g_ev_start = ev[2 * i];
         g_ev_stop = ev[2 * i + 1];
-        switch (kernel_id) {
-            case 0: rc = launch_ffn_fused(s->hb, s->x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden); break;
-            case 1: rc = q4_matmul_q4(s->hb, s->xb, &L->wq_gate, dim, hidden, 0, -1, nullptr); break;
-            case 2: rc = q4_matmul_q4(s->xb, s->hb, &L->wq_down, hidden, dim, 1, -1, nullptr); break;
-            case 3: rc = launch_qkv_fused(s->q, s->key_cache, s->value_cache, s->x, L->rms_att_weight, &L->wq_q, &L->wq_k,
-                                          &L->wq_v, dim, kv_dim, loff, s->pos, head_size, p->rope_theta, rope_table_of(s), nullptr); break;
-            case 4: rc = q4_matmul_q4(s->q, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr); break;
-            case 5: rc = q4_matmul_f16(s->logits, s->x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f); break;
-            case 6: rc = q4_multi_head_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, s->att, p->n_heads,
-                                                 head_size, p->n_heads / p->n_kv_heads, p->seq_len, s->pos); break;
-            default: rc = Q4_ERR_ARG;
-        }
+        rc = launch_by_id(kernel_id, i, p, s, w, true);
     }
     g_ev_start = g_ev_stop = nullptr;
     double total = 0, mn = 1e30, mx = 0;

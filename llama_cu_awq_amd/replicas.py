@@ -13,11 +13,6 @@ def init(backend, rank, world_size, device=None):
     return dist
 
 
-def shard_prompts(prompts, rank, world_size):
-    """Independent sequences are dealt round-robin: replica r decodes prompts[r::world_size]."""
-    return prompts[rank::world_size]
-
-
 def aggregate(elapsed_s, tokens, dist=None, device="cpu"):
     """(max over ranks of elapsed, sum over ranks of tokens): whole-job tokens/s = tokens_sum / elapsed_max."""
     if dist is None:

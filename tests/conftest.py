@@ -33,6 +33,20 @@ def q4():
     L.q4_stream_destroy(s)
 
 
+@pytest.fixture(autouse=True)
+def _library_at_its_default_fusion_level(request):
+    """Every GPU test starts at the library's default fusion level: a test that changed it and did not put it back, or a timed-out
+    hand-off in an earlier test (the library then sits out some sequences at level 1), must not let later tests run at another
+    level than they believe they cover."""
+    if "q4" in request.fixturenames:
+        api = request.getfixturevalue("q4")
+        L = api.lib()
+        if L.q4_get_fusion() != api.DEFAULT_FUSION:
+            L.q4_set_fusion(api.DEFAULT_FUSION)
+            pytest.fail("the previous test left the library at fusion level != %d" % api.DEFAULT_FUSION)
+    yield
+
+
 @pytest.fixture(scope="session")
 def orc():
     import oracle

@@ -13,8 +13,9 @@ against the CPU restatement (oracle/q4_oracle.c) and the unrounded double forwar
 
 Tolerances. At 32-40 layers of RANDOM weights two valid fp16 evaluations of the network drift apart by a few 1e-2 of
 max(1,|logit|); the yardstick is the same network in double without rounding (orc_forward_f64): the HIP path may be at
-most 2x as far from it as the reference-order restatement (+1e-3). Against the restatement itself the bound is 3x the
-measured worst case (0.050 at 7B, 0.059 at 13B: profiles/r02_parity_observed.json -> 0.15). Tokens must be equal except at near-ties of the restatement's top two logits."""
+most 2x as far from it as the reference-order restatement (+1e-3). Against the restatement itself the bound is 2x the
+measured worst case PER GEOMETRY (BOUND below; profiles/r04_parity_observed.json keeps every position's value). Tokens must be
+equal except at near-ties of the restatement's top two logits."""
 import ctypes as C
 import os
 
@@ -28,6 +29,10 @@ pytestmark = pytest.mark.gpu
 PROMPT = [1, 2436, 385, 3686, 388, 1048, 22796, 118]      # "write an essay about GPUs", reference tokenizer
 PROMPT_SMALL = [1, 17, 300, 45, 9]                         # for the 512-entry vocabularies of the test-size models
 MODEL_DIR = os.environ.get("Q4_MODEL_DIR", "/tmp")
+# logits vs the reference-order restatement, max |d| / max(1, |logit|), per geometry: 2x the worst value the round's runs measured
+# (profiles/r04_parity_observed.json: 7B 0.050 over 32 positions and 0.033 at the config-4 checkpoints, 13B 0.068 over 24 positions
+# and 0.051 at position 200, Mistral-shaped 0.041, perplexity path 0.046)
+BOUND = {"7b": 0.10, "13b": 0.14, "mistral7b": 0.085}
 
 
 def _model(name):
@@ -60,6 +65,7 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement, rec=None
     ring = _ring(t)
     toks = list(prompt)
     worst, compared, ties = 0.0, 0, 0
+    per_pos = []
     for pos in range(steps):
         gen = pos >= len(prompt) - 1
         t.run_transformer(gen)
@@ -68,6 +74,7 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement, rec=None
         got = t.logits()
         e = _rel(got, ref)
         worst = max(worst, e)
+        per_pos.append(round(e, 5))
         assert e <= bound_vs_restatement, "pos %d: max rel logit err %g vs the restatement" % (pos, e)
         if pos < f64_steps:
             exact = m.forward_f64(toks[pos], pos, cap=f64_steps)
@@ -89,14 +96,15 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement, rec=None
             compared += 1
             toks.append(want)
     if rec is not None:
-        rec.update({"logits_max_rel_vs_restatement": worst, "tokens_compared": compared, "near_ties": ties, "positions": steps})
+        rec.update({"logits_max_rel_vs_restatement": worst, "tokens_compared": compared, "near_ties": ties, "positions": steps,
+                    "per_position_vs_restatement": per_pos, "bound": bound_vs_restatement})
     return worst, compared, ties
 
 
 def test_config2_llama2_7b_decode_32_positions(q4, orc, m7b, observed):
     t = q4.Transformer(m7b)
     m = orc.Model(m7b)
-    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 32, 32, bound_vs_restatement=0.15,   # measured 0.027-0.05
+    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 32, 32, bound_vs_restatement=BOUND["7b"],
                                      rec=observed.setdefault("config2_7b", {}))
     assert compared == 25 and ties <= 2
     # KV rows of the last position: layer 0 sees only the embedding (one GEMV deep), the last layer the whole stack
@@ -112,7 +120,7 @@ def test_config3_llama2_13b_decode_24_positions(q4, orc, observed):
     path = _model("13b")
     t = q4.Transformer(path)
     m = orc.Model(path)
-    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 24, 12, bound_vs_restatement=0.15, rec=observed.setdefault("config3_13b", {}))
+    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 24, 24, bound_vs_restatement=BOUND["13b"], rec=observed.setdefault("config3_13b", {}))
     assert compared == 17 and ties <= 2
     t.close()
     m.close()
@@ -122,7 +130,7 @@ def test_grouped_query_model_at_mistral_7b_geometry(q4, orc, observed):
     path = _model("mistral7b")
     t = q4.Transformer(path)
     m = orc.Model(path)
-    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 24, 8, bound_vs_restatement=0.15, rec=observed.setdefault("mistral7b_gqa", {}))
+    worst, compared, ties = _lockstep(q4, t, m, PROMPT, 24, 8, bound_vs_restatement=BOUND["mistral7b"], rec=observed.setdefault("mistral7b_gqa", {}))
     assert compared == 17 and ties <= 2
     t.close()
     m.close()
@@ -140,7 +148,7 @@ def _kv_to_host(q4, t):
     return k, v
 
 
-def _step_from_the_gpus_cache(q4, orc, path, target, observed, key):
+def _step_from_the_gpus_cache(q4, orc, path, target, observed, key, bound=BOUND["7b"]):
     """Decode `target` positions through run_transformer's captured graphs (every sequence-length bin up to 2048: bin 256 with
     four attention blocks per head, one V slice each, the split-context attention from bin 512 on), then compare ONE more
     step with the restatement started from the GPU's own KV cache -- no 2000-step CPU run, and every cached position takes
@@ -172,7 +180,8 @@ def _step_from_the_gpus_cache(q4, orc, path, target, observed, key):
         assert ek <= ktol and ev <= vtol, (layer, ek, ev)
     e = _rel(got, ref)
     rec["logits_max_rel_vs_restatement"] = e
-    assert e <= 0.15, e
+    rec["bound"] = bound
+    assert e <= bound, e
     r32 = ref.astype(np.float32)
     top2 = np.sort(r32)[-2:]
     if top2[1] - top2[0] > 4e-3 * max(1.0, abs(top2[1])):
@@ -218,7 +227,7 @@ def test_bins_above_2048_end_to_end(q4, orc, tmp_path_factory, observed, name, f
         ref = m.forward(tok, target)
         e = _rel(got, ref)
         observed["%s_fusion%d_pos%d" % (name, fusion, target)] = {"logits_max_rel_vs_restatement": e, "tok_s_to_target": tps}
-        assert e <= 1.2e-2, e          # two layers deep: measured <= 4e-3 (profiles/r04_parity_observed.json)
+        assert e <= 3e-3, e            # two layers deep: measured <= 1.0e-3, one fp16 ulp of an O(1) logit (profiles/r04_parity_observed.json)
         rk, rv = m.kv()
         for layer in range(t.config.n_layers):
             gk, gv = t.kv_row(layer, target)
@@ -236,7 +245,13 @@ def test_bins_above_2048_end_to_end(q4, orc, tmp_path_factory, observed, name, f
 def test_llama2_13b_inside_bin_256(q4, orc, observed):
     """The same comparison at the 13B geometry inside bin 256 (K = 5120 in three k-slots with a shared half slot, 40 heads x
     4 V-slice attention blocks, 160 o-proj blocks)."""
-    _step_from_the_gpus_cache(q4, orc, _model("13b"), 200, observed, "config3_13b")
+    _step_from_the_gpus_cache(q4, orc, _model("13b"), 200, observed, "config3_13b", bound=BOUND["13b"])
+
+
+def test_llama2_13b_inside_bin_1024(q4, orc, observed):
+    """... and inside bin 1024 (split-context attention: 40 heads x eight 128-position chunks, records as granules, merged by each
+    head's first chunk block), position 600."""
+    _step_from_the_gpus_cache(q4, orc, _model("13b"), 600, observed, "config3_13b", bound=BOUND["13b"])
 
 
 def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b, observed):
@@ -253,7 +268,7 @@ def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b, observed):
         exact = m.forward_f64(int(toks[i]), i, cap=n64)
         eg, er = _rel(glog[i], exact), _rel(rlog[i], exact)
         assert eg <= 2.0 * er + 1e-3, (i, eg, er)
-    assert _rel(glog, rlog) <= 0.15
+    assert _rel(glog, rlog) <= BOUND["7b"]
     rppl = orc.compute_perplexity(toks[1:npos + 1], rlog)
     observed["config5_7b_perplexity"] = {"positions": npos, "perplexity_gpu": float(ppl), "perplexity_restatement": float(rppl),
                                          "logits_max_rel_vs_restatement": _rel(glog, rlog)}

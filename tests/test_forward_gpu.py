@@ -80,7 +80,7 @@ def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
                                                      ("tinyllama", 1060, (3, 100, 127, 128, 200, 255, 256, 300, 511, 512, 600, 1023, 1024, 1059)),
                                                      ("head256", 590, (3, 100, 127, 128, 255, 256, 511, 512, 589)),
                                                      ("head128_k8192", 290, (3, 127, 128, 200, 255, 256, 289))])
-def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name, steps, checkpoints):
+def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, observed, name, steps, checkpoints):
     """Fusion level 3 (attention -> o-proj as ONE launch, the hand-off inside the launch) against levels 1 and 0 across the
     sequence-length bins 128 / 256 (one block per head) and 512 / 1024 / seq_len (split context), for heads of 64 / 128 / 256,
     multi-head and grouped-query, K = dim in one, two, three (shared half slot) and four k-slots: the same arithmetic with the
@@ -112,9 +112,13 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, name,
     # (the stand-alone kernel: 4), and with 8 waves where the stand-alone kernel of the other head sizes has 16 -- so the
     # comparison is the model's bound with equal greedy token rings. (The one-block form of the role, which reproduces level 1
     # bit for bit in the first bin, is compared in tests/prof_cases.py.)
+    first_div = next((i for i, (x, y) in enumerate(zip(outs[1][1], outs[3][1])) if x != y), None)
+    observed.setdefault("fusion3_vs_1_first_token_divergence", {})[name] = first_div
+    # a near-tie may resolve the other way under another fp32 grouping, but not inside the first bin: measured first divergences
+    # 300+ or none (profiles/r04_parity_observed.json)
+    assert first_div is None or first_div >= 128, "token rings diverged at %d (fusion 3 vs 1)" % first_div
     for a, b, pos in zip(outs[1][0], outs[3][0], checkpoints):
-        if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:    # a near-tie resolved the other way under another fp32 grouping
-            assert pos >= 60, "token rings diverged early (%d, fusion 3)" % pos
+        if first_div is not None and pos >= first_div:
             break
         af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
         err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())
