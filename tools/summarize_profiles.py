@@ -123,3 +123,28 @@ traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate pa
                    "streaming reads at 64 B (MI355X_MICROARCH.md, HBM section): doubled before comparing with byte counts. Kernels that read "
                    "narrower than 16 B per lane (attention merges, argmax) are outside that calibration.")
 json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
+
+
+# SQ counters of the gate/up launch run alone (tools/prof_kernel.py 0): VALU instruction count and VALU-busy time per launch -- the
+# evidence behind "the int4 GEMV is VALU-bound" 
+sq = defaultdict(list)
+meta = {}
+for f in glob.glob(os.path.join(src, "pmc_k0_sq", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemv_q4_kernel<2" in r["Kernel_Name"] or "ffn_engine_kernel" in r["Kernel_Name"]:
+            sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {"kernel": short(r["Kernel_Name"]), "vgpr": int(r["VGPR_Count"]), "workgroup": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
+if sq:
+    out = {k: round(sum(v) / len(v), 1) for k, v in sq.items()}
+    out.update(meta)
+    out["launches"] = len(next(iter(sq.values())))
+    if "SQ_ACTIVE_INST_VALU" in out and "SQ_INSTS_VALU" in out:
+        simds = 1024
+        out["valu_busy_cycles_per_simd"] = round(4.0 * out["SQ_ACTIVE_INST_VALU"] / simds, 1)   # the counter ticks in quad-cycles
+        out["cycles_per_valu_instruction"] = round(4.0 * out["SQ_ACTIVE_INST_VALU"] / out["SQ_INSTS_VALU"], 2)
+        out["valu_instructions_per_wave"] = round(out["SQ_INSTS_VALU"] / max(1.0, out.get("SQ_WAVES", 1.0)), 1)
+    out["note"] = ("rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES over "
+                   "tools/prof_kernel.py 0 32 (the fused gate/up launch over the ring of the layers' weights); SQ_ACTIVE_INST_VALU counts quad-cycles "
+                   "summed over the chip's 1024 SIMDs (MI355X_MICROARCH.md, per-instruction constants)")
+    json.dump(out, open(os.path.join(dst, "%s_sq_counters_gate_up.json" % tag), "w"), indent=1)
+    print("gate/up SQ counters:", json.dumps(out)[:400])
