@@ -162,6 +162,12 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
         L.q4_set_gemv_early(9, 1)
         ppl = t.perplexity_ids(ptoks)
         assert ppl == want_ppl and L.q4_handoff_timeouts() == 2 and L.q4_get_fusion() == 1
+        # probation: the second time-out sits out 32 sequences (16 after the first, doubled), counted by q4_reset_sequence -- the
+        # redo of the failed sequence was the first of them --, then level 3 is tried again by itself, with clean results
+        for i in range(30):
+            assert np.array_equal(t.generate_ids(prompt, 12)[0], want[:13]) and L.q4_get_fusion() == 1, i
+        assert np.array_equal(t.generate_ids(prompt, 40)[0][:12], want[:12])
+        assert L.q4_get_fusion() == 3 and L.q4_handoff_timeouts() == 2
         t.close()
     finally:
         L.q4_set_gemv_early(9, 0)
