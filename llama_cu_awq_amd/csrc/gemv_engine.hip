@@ -1,8 +1,10 @@
-// gemv_engine.hip -- EXPERIMENT, profiling build only (q4_set_gemv_early(11, lag)): the fused gate/up GEMV as a loader / consumer
-// engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as
-// gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit.
-// The shipped library does not contain it: measured on MI355X (profiles/r04_engine_*.txt) it streams at
-// 7.5 TB/s and still ends where the shipped kernel ends, because the int4 dequant-dot is VALU work, not bandwidth.
+// gemv_engine.hip -- the fused gate/up GEMV at K = 4096 (Llama-2-7B, Mistral-7B shapes) as a loader / consumer engine on LDS-DMA
+// (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as gemv_q4_kernel<MODE_FFN>
+// (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit (tests/prof_cases.py compares the two
+// forms); other shapes, CU-masked streams and ablation builds run gemv_q4_kernel.
+// Measured on MI355X (profiles/r04_engine_records.txt): 9.30 us against 9.47-9.76 us per launch by HIP
+// events, +0.8 % tokens/s at 7B -- NOT the 8.6 us the stream alone would allow (it lands the 47 MB in 7.0 us at 7.5 TB/s): the
+// int4 dequant-dot is VALU work, and what the engine saves is the x staging (once per CU instead of once per 8-column block).
 //
 // Idea: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded by its VGPRs, no
 // weight request goes out before the x chain of its block has been scheduled around, and every block re-stages x. Here one block
@@ -31,11 +33,9 @@
 
 namespace q4 {
 
-int g_engine = 0;   // 0: gemv_q4_kernel<MODE_FFN>; 1..3: the engine with LAG = value, where the shape is covered
+int g_engine = 1;   // 0: gemv_q4_kernel<MODE_FFN> everywhere; 1..3: the engine with LAG = value where the shape is covered (1 measured best)
 
-#ifdef Q4_PROFILING
-
-constexpr int ENG_CONSUMERS = 8, ENG_RING = 8, ENG_NQMAX = 12;
+constexpr int ENG_CONSUMERS = 8, ENG_RING = 8, ENG_NQMAX = 14;   // 14 quads per CU: hidden_dim up to 14336 on 256 CUs
 
 template <int KSL>
 struct EngLds {
@@ -53,7 +53,7 @@ struct EngLds {
     static constexpr unsigned BYTES = FLAGS + 64u;
     static_assert(ENG_NQMAX * 32u * KSL <= SIDE_Z_BYTES, "zeros of the block's range: one DMA instruction per matrix");
 };
-enum { F_LANDED = 0, F_CONSUMED = 1, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4 };
+enum { F_LANDED = 0, F_CONSUMED = 1, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4, F_FAIL = 5 };
 
 // one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
 // M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
@@ -84,24 +84,34 @@ __device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
     if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
-// every wait is bounded (~0.2 s): a protocol error must end as wrong numbers in a test, never as a hung GPU
-constexpr unsigned ENG_SPIN_LIMIT = 1u << 21;
-__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target) {
+// Every wait is on a wave of the SAME block (all resident by construction: no scheduling order can wedge it), and still bounded
+// (~10 s): a wait that runs out -- a logic error, not a race -- raises the block's fail word, and the block then stores NaN, so the
+// failure is loud in every consumer of the result instead of a hung GPU or plausible garbage.
+constexpr unsigned ENG_SPIN_LIMIT = 1u << 27;
+__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target, unsigned* fail) {
     unsigned v = lds_peek(p);
-    for (unsigned n = 0; v < target && n < ENG_SPIN_LIMIT; n++) { __builtin_amdgcn_s_sleep(1); v = lds_peek(p); }
+    for (unsigned n = 0; v < target; n++) {
+        if (n >= ENG_SPIN_LIMIT || ((n & 1023u) == 1023u && lds_peek(fail) != 0u)) { lds_post(fail, 1u, 0u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = lds_peek(p);
+    }
     return v;
 }
 // barrier among the consumer waves only (the loader keeps issuing)
-__device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane) {
+__device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, unsigned* fail) {
     lds_bump(cnt, lane);
-    lds_wait_ge(cnt, (unsigned)ENG_CONSUMERS);
+    lds_wait_ge(cnt, (unsigned)ENG_CONSUMERS, fail);
 }
 
 // wall-clock stamps (100 MHz, the same counter on every XCD) of one block's loader and of its consumer wave 0, 64 words per
 // block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry, [17] x staged,
 // [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored (tools/timeline_engine.py).
 // A stamp is a global store: it counts in the loader's vmcnt, so stamped runs of LAG = 1 stall on their own stamps.
+#ifdef Q4_PROFILING
 #define ENG_STAMP(k) do { if (STAMPS && a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
+#else
+#define ENG_STAMP(k) do { } while (0)
+#endif
 
 template <int KSL, bool NORM, int LAG, bool STAMPS>
 __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(const GemvArgs a, const unsigned qbase, const unsigned qrem) {
@@ -143,7 +153,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         }
         ENG_STAMP(1);
         for (int j = 0; j < nq; j++) {
-            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONSUMED], (unsigned)(ENG_CONSUMERS * (j - ENG_RING + 1)));
+            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONSUMED], (unsigned)(ENG_CONSUMERS * (j - ENG_RING + 1)), &flags[F_FAIL]);
             const unsigned slot = L::RING + (unsigned)(j % ENG_RING) * L::SLOT;
             const unsigned soff = (q0 + (unsigned)j) * (L::SLOT / 2u);
 #pragma unroll
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         float ss = 1.f;
         if (NORM) {
             part[tid] = sumsq8(xraw, 0.f);
-            consumer_barrier(&flags[F_BAR0], lane);
+            consumer_barrier(&flags[F_BAR0], lane, &flags[F_FAIL]);
             ss = rms_scale_from_partials<KSL * 256>(part, KSL * 256, a.K);
         }
         u32x4 v = xraw;
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         const unsigned j = tid >> 2, d = tid & 3u;
         xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
         if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
-        consumer_barrier(&flags[F_BAR1], lane);
+        consumer_barrier(&flags[F_BAR1], lane, &flags[F_FAIL]);
     }
     if (wave == 0) ENG_STAMP(17);
     u32x4 X[KSL][4];
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         for (int r = 0; r < 4; r++) {
             const int i = g4 * 4 + r;
             if (i < nq) {
-                if (known <= (unsigned)i) known = lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u);
+                if (known <= (unsigned)i) known = lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u, &flags[F_FAIL]);
                 if (wave == 0) ENG_STAMP(18 + i);
                 const unsigned char* sl = wbase + (unsigned)(i % ENG_RING) * L::SLOT;
                 u32x4 W[KSL];
@@ -258,7 +268,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         const int row = lane >> 4;
         if ((lane & 15u) == 0 && g4 * 4 + row < nq) tot[(g4 * 4 + row) * 8 + wave] = total;
     }
-    consumer_barrier(&flags[F_BAR2], lane);
+    consumer_barrier(&flags[F_BAR2], lane, &flags[F_FAIL]);
     if (wave == 0) ENG_STAMP(44);
     if ((int)tid < nq * 4) {
         const int i = tid >> 2, c = tid & 3;
@@ -266,16 +276,17 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         float val = g;
         val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
         val *= u;                                       // :272
-        a.out[0][(q0 + i) * 4 + c] = f2h(val);
+        a.out[0][(q0 + i) * 4 + c] = lds_peek(&flags[F_FAIL]) != 0u ? (uint16_t)0x7E00u : f2h(val);   // (NaN: a wait ran out)
     }
     if (wave == 0) ENG_STAMP(45);
 }
 #undef ENG_STAMP
 
 // the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
+// ... on a stream that may use every CU (one 147 KiB block per CU: on a CU-masked stream the blocks would queue behind each other)
 bool ffn_engine_covers(const GemvArgs& a) {
-    return g_engine >= 1 && g_engine <= 3 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
-           divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count();
+    return g_engine >= 1 && g_engine <= 3 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+           divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count() && stream_cu_count() == cu_count();
 }
 
 template <int KSL, bool NORM, int LAG, bool STAMPS>
@@ -303,15 +314,10 @@ static int launch_engine_lag(const GemvArgs& a) {
 
 int launch_ffn_engine(const GemvArgs& a) {
     const bool norm = a.rms_w != nullptr;
+#ifdef Q4_PROFILING
     if (a.dbg) return norm ? launch_engine_lag<true, true>(a) : launch_engine_lag<false, true>(a);
+#endif
     return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);
 }
-
-#else    // the shipped library: no engine
-
-bool ffn_engine_covers(const GemvArgs&) { return false; }
-int launch_ffn_engine(const GemvArgs&) { return Q4_ERR_UNSUPPORTED_SIZE; }
-
-#endif
 
 }  // namespace q4

@@ -18,7 +18,7 @@ int g_ao_guard = 1;   // profiling build: q4_set_gemv_early(8, 0) admits grids l
 // CUs the launch stream may use: all of the device, or the bits of its CU mask (hipExtStreamCreateWithCUMask)
 static std::map<hipStream_t, int>& stream_cu_cache() { static std::map<hipStream_t, int> c; return c; }
 void attention_oproj_forget_stream(hipStream_t s) { stream_cu_cache().erase(s); }   // q4_stream_destroy: the handle may be reused
-static int stream_cu_count() {
+int stream_cu_count() {
     std::map<hipStream_t, int>& cache = stream_cu_cache();
     auto it = cache.find(g_stream);
     if (it != cache.end()) return it->second;

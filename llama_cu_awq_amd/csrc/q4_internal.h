@@ -88,6 +88,7 @@ enum { SYNC_ERROR = 0, SYNC_EPOCH = 1, SYNC_ARRIVE = 128, SYNC_MAX_HEADS = 512, 
 extern int g_ao_mute;
 size_t attention_sync_words(int dim);
 void attention_oproj_forget_stream(hipStream_t s);
+int stream_cu_count();       // CUs the launch stream may use (all of the device, or the bits of its CU mask)
 int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int seq_len_bin, bool have_scratch, size_t scratch_bytes,
                          int split_min, int split_chunk);   // >= 0: the fused attention + o-proj launch covers this case
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,

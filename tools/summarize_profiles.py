@@ -61,7 +61,7 @@ def algorithmic(kernel, model, ntok):
     """algorithmic bytes per launch of a kernel of the decode network (weights + metadata + vectors in / out)"""
     d, h, v, _ = GEOM[model]
     kernel = kernel[4:] if kernel.startswith("q4::") else kernel
-    if kernel.startswith("gemv_q4_kernel<2"):
+    if kernel.startswith("gemv_q4_kernel<2") or kernel.startswith("ffn_engine_kernel"):
         return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
     if kernel.startswith("gemv_q4_kernel<1"):
         return 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2
@@ -115,7 +115,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
     print(model, ntok, json.dumps(per)[:600])
 if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
     for k, e in traffic["7b_n256"].items():
-        if k.replace("q4::", "").startswith("gemv_q4_kernel<2"):
+        if k.replace("q4::", "").startswith("gemv_q4_kernel<2") or k.replace("q4::", "").startswith("ffn_engine_kernel"):
             traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
 traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
