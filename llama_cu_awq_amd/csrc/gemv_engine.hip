@@ -1,10 +1,10 @@
-// gemv_engine.hip -- the fused gate/up GEMV at K = 4096 (Llama-2-7B, Mistral-7B shapes) as a loader / consumer engine on LDS-DMA
-// (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as gemv_q4_kernel<MODE_FFN>
-// (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit (tests/prof_cases.py compares the two
-// forms); other shapes, CU-masked streams and ablation builds run gemv_q4_kernel.
-// Measured on MI355X (profiles/r04_engine_records.txt): 9.30 us against 9.47-9.76 us per launch by HIP
-// events, +0.8 % tokens/s at 7B -- NOT the 8.6 us the stream alone would allow (it lands the 47 MB in 7.0 us at 7.5 TB/s): the
-// int4 dequant-dot is VALU work, and what the engine saves is the x staging (once per CU instead of once per 8-column block).
+// gemv_engine.hip -- EXPERIMENT, profiling build only (q4_set_gemv_early(11, lag)): the fused gate/up GEMV at K = 4096 as a
+// loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic
+// as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit
+// (tests/prof_cases.py compares the two forms). The shipped library does not contain it: measured on MI355X (DESIGN.md section 9
+// item 12, profiles/r04_engine_records.txt) it lands the 47 MB in 7.0 us at 7.5 TB/s and still ends where the shipped kernel
+// ends -- 9.69-9.73 against 9.72-9.76 us per launch by rocprofv3 in one call, 955.7 against 961.3 tokens/s in the token loop --
+// because the int4 dequant-dot is VALU work, not bandwidth.
 //
 // Idea: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded by its VGPRs, no
 // weight request goes out before the x chain of its block has been scheduled around, and every block re-stages x. Here one block
@@ -26,14 +26,18 @@
 //            so fills <= j - LAG have landed -- and stores j + 1 - LAG; at the end it drains LAG-1 .. 0. vmcnt is a 6-bit
 //            counter, so a wave has at most 64 KiB of 1 KiB pieces in flight: LAG <= 3, and what the loader may have in flight
 //            is exactly what it cannot know to have landed.
-//   consumed (LDS word) += 1 by each consumer wave once its ds_reads of a slot have been executed; the loader refills slot j % 8
-//            when consumed >= 8 * (j - 7).
+//   read[w]  (one LDS word per consumer wave) = slots wave w has read, stored by the wave once its ds_reads of a slot have been
+//            executed; the loader refills slot j % 8 when every read[w] >= j - 7 (a single running total would not do: the waves
+//            are not in lock step, four of them two slots ahead count like eight of them one slot ahead).
 //   consumer-only barriers of the x chain: one LDS counter each.
 #include "gemv_q4.h"
 
 namespace q4 {
 
-int g_engine = 1;   // 0: gemv_q4_kernel<MODE_FFN> everywhere; 1..3: the engine with LAG = value where the shape is covered (1 measured best)
+int g_engine = 0;   // 0: gemv_q4_kernel<MODE_FFN> everywhere (the product); 1..3: the engine with LAG = value where the shape is covered (1 measured best);
+                    // 5, 6 = LAG 1, 2 with the consumers' next-slot prefetch
+
+#ifdef Q4_PROFILING
 
 constexpr int ENG_CONSUMERS = 8, ENG_RING = 8, ENG_NQMAX = 14;   // 14 quads per CU: hidden_dim up to 14336 on 256 CUs
 
@@ -53,7 +57,7 @@ struct EngLds {
     static constexpr unsigned BYTES = FLAGS + 64u;
     static_assert(ENG_NQMAX * 32u * KSL <= SIDE_Z_BYTES, "zeros of the block's range: one DMA instruction per matrix");
 };
-enum { F_LANDED = 0, F_CONSUMED = 1, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4, F_FAIL = 5 };
+enum { F_LANDED = 0, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4, F_FAIL = 5, F_READ0 = 8 };   // [F_READ0 + w]: slots consumer wave w has read
 
 // one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
 // M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
@@ -97,6 +101,16 @@ __device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target, un
     }
     return v;
 }
+// the loader's wait for a ring slot: all ENG_CONSUMERS per-wave counts (one word each, lanes 0..7 read one apiece) >= target
+__device__ __forceinline__ void lds_wait_all_ge(unsigned* p, unsigned target, unsigned lane, unsigned* fail) {
+    for (unsigned n = 0;; n++) {
+        const unsigned v = lane < (unsigned)ENG_CONSUMERS ? __hip_atomic_load(p + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
+        asm volatile("" ::: "memory");
+        if (__ballot(v < target) == 0ull) break;
+        if (n >= ENG_SPIN_LIMIT || ((n & 1023u) == 1023u && lds_peek(fail) != 0u)) { lds_post(fail, 1u, 0u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 // barrier among the consumer waves only (the loader keeps issuing)
 __device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, unsigned* fail) {
     lds_bump(cnt, lane);
@@ -107,13 +121,9 @@ __device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, u
 // block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry, [17] x staged,
 // [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored (tools/timeline_engine.py).
 // A stamp is a global store: it counts in the loader's vmcnt, so stamped runs of LAG = 1 stall on their own stamps.
-#ifdef Q4_PROFILING
 #define ENG_STAMP(k) do { if (STAMPS && a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
-#else
-#define ENG_STAMP(k) do { } while (0)
-#endif
 
-template <int KSL, bool NORM, int LAG, bool STAMPS>
+template <int KSL, bool NORM, int LAG, bool STAMPS, bool PF>
 __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(const GemvArgs a, const unsigned qbase, const unsigned qrem) {
     static_assert(KSL == 2, "x staging: one 8-half chunk per consumer thread (K = 4096)");
     static_assert(LAG >= 1 && 8 * KSL * LAG <= 48, "vmcnt is 6 bits");
@@ -153,7 +163,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         }
         ENG_STAMP(1);
         for (int j = 0; j < nq; j++) {
-            if (j >= ENG_RING) lds_wait_ge(&flags[F_CONSUMED], (unsigned)(ENG_CONSUMERS * (j - ENG_RING + 1)), &flags[F_FAIL]);
+            if (j >= ENG_RING) lds_wait_all_ge(&flags[F_READ0], (unsigned)(j - ENG_RING + 1), lane, &flags[F_FAIL]);   // every wave has read the slot's previous fill
             const unsigned slot = L::RING + (unsigned)(j % ENG_RING) * L::SLOT;
             const unsigned soff = (q0 + (unsigned)j) * (L::SLOT / 2u);
 #pragma unroll
@@ -220,6 +230,26 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
     const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)col * (2u * KSL) + (lane >> 5)) * 4u;
     const unsigned zsh = ((lane >> 2) & 7u) * 4u;      // nibble of this lane's group in its zeros word (16 groups per k-slot)
     unsigned known = 0;                                // fills this wave has seen landed: the flag is read again only past it
+    // the reads of one slot: this wave's two weight pieces, their scales and zero words; then the slot's release -- a slot is
+    // free once every consumer's reads have been executed, and LDS executes a wave's operations in order: the bump follows them
+    auto read_slot = [&](int i, u32x4 (&W)[KSL], unsigned (&zw)[KSL], uint16_t (&sc)[KSL]) {
+        const unsigned char* sl = wbase + (unsigned)(i % ENG_RING) * L::SLOT;
+#pragma unroll
+        for (int ks = 0; ks < KSL; ks++) {             // group of unit ks * 64 + lane = ks * 16 + lane / 4
+            W[ks] = *reinterpret_cast<const u32x4*>(sl + ks * 1024);
+            sc[ks] = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (128u * KSL) + ks * 32);
+            zw[ks] = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (32u * KSL) + ks * 8);
+        }
+        lds_post(&flags[F_READ0 + wave], (unsigned)i + 1u, lane);   // (a plain store of this wave's own count: no atomic, no contention)
+    };
+    // PF (measured, off): the NEXT slot's reads go out before the current slot is multiplied whenever that slot has landed already
+    // (one look at the flag, no waiting), to hide their LDS latency under ~100 VALU instructions. Slower -- 10.17 against 9.68 us
+    // by rocprofv3, 940.7 against 952.2 tokens/s in one call: the register copies and the second flag read are VALU work too, and
+    // a wave that runs ahead takes issue slots from the wave whose slot is due.
+    u32x4 Wn[KSL];
+    unsigned zn[KSL];
+    uint16_t sn[KSL];
+    bool have_next = false;
 
     for (int g4 = 0; g4 * 4 < nq; g4++) {
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -227,20 +257,22 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         for (int r = 0; r < 4; r++) {
             const int i = g4 * 4 + r;
             if (i < nq) {
-                if (known <= (unsigned)i) known = lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u, &flags[F_FAIL]);
-                if (wave == 0) ENG_STAMP(18 + i);
-                const unsigned char* sl = wbase + (unsigned)(i % ENG_RING) * L::SLOT;
                 u32x4 W[KSL];
                 unsigned zw[KSL];
                 uint16_t sc[KSL];
+                if (PF && have_next) {
 #pragma unroll
-                for (int ks = 0; ks < KSL; ks++) {     // group of unit ks * 64 + lane = ks * 16 + lane / 4
-                    W[ks] = *reinterpret_cast<const u32x4*>(sl + ks * 1024);
-                    sc[ks] = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (128u * KSL) + ks * 32);
-                    zw[ks] = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (32u * KSL) + ks * 8);
+                    for (int ks = 0; ks < KSL; ks++) { W[ks] = Wn[ks]; zw[ks] = zn[ks]; sc[ks] = sn[ks]; }
+                } else {
+                    if (known <= (unsigned)i) known = lds_wait_ge(&flags[F_LANDED], (unsigned)i + 1u, &flags[F_FAIL]);
+                    read_slot(i, W, zw, sc);
                 }
-                // the slot is free once every consumer's reads have been executed (LDS order: the bump follows them)
-                lds_bump(&flags[F_CONSUMED], lane);
+                if (wave == 0) ENG_STAMP(18 + i);
+                have_next = false;
+                if (PF && i + 1 < nq) {
+                    if (known <= (unsigned)i + 1u) known = lds_peek(&flags[F_LANDED]);
+                    if (known > (unsigned)i + 1u) { read_slot(i + 1, Wn, zn, sn); have_next = true; }
+                }
                 float c = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KSL; ks++) {
@@ -285,39 +317,47 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
 // the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
 // ... on a stream that may use every CU (one 147 KiB block per CU: on a CU-masked stream the blocks would queue behind each other)
 bool ffn_engine_covers(const GemvArgs& a) {
-    return g_engine >= 1 && g_engine <= 3 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+    return g_engine >= 1 && g_engine <= 7 && g_engine != 4 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
            divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count() && stream_cu_count() == cu_count();
 }
 
-template <int KSL, bool NORM, int LAG, bool STAMPS>
+template <int KSL, bool NORM, int LAG, bool STAMPS, bool PF>
 static int launch_engine(const GemvArgs& a) {
     static bool opted = false;
     constexpr size_t smem = EngLds<KSL>::BYTES;
     if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, STAMPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         opted = true;
     }
     const unsigned nquads = (unsigned)a.N >> 2, nb = (unsigned)cu_count();
-    Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, STAMPS>), dim3(nb), dim3((ENG_CONSUMERS + 1) * 64), smem, a, nquads / nb, nquads % nb);
+    Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, STAMPS, PF>), dim3(nb), dim3((ENG_CONSUMERS + 1) * 64), smem, a, nquads / nb, nquads % nb);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
 
 template <bool NORM, bool STAMPS>
 static int launch_engine_lag(const GemvArgs& a) {
-    switch (g_engine) {
-        case 1: return launch_engine<2, NORM, 1, STAMPS>(a);
-        case 2: return launch_engine<2, NORM, 2, STAMPS>(a);
-        default: return launch_engine<2, NORM, 3, STAMPS>(a);
+    switch (g_engine) {        // + 4: WITH the next-slot prefetch (profiling build; measured slower: 10.2 against 9.7 us)
+        case 1: return launch_engine<2, NORM, 1, STAMPS, false>(a);
+        case 2: return launch_engine<2, NORM, 2, STAMPS, false>(a);
+        case 3: return launch_engine<2, NORM, 3, STAMPS, false>(a);
+        case 5: return launch_engine<2, NORM, 1, STAMPS, true>(a);
+        case 6: return launch_engine<2, NORM, 2, STAMPS, true>(a);
+        default: return launch_engine<2, NORM, 3, STAMPS, false>(a);
     }
 }
 
 int launch_ffn_engine(const GemvArgs& a) {
     const bool norm = a.rms_w != nullptr;
-#ifdef Q4_PROFILING
     if (a.dbg) return norm ? launch_engine_lag<true, true>(a) : launch_engine_lag<false, true>(a);
-#endif
     return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);
 }
+
+#else    // the shipped library: no engine
+
+bool ffn_engine_covers(const GemvArgs&) { return false; }
+int launch_ffn_engine(const GemvArgs&) { return Q4_ERR_UNSUPPORTED_SIZE; }
+
+#endif
 
 }  // namespace q4

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N", [11008, 14336, 1024 * 4 + 8, 4096])
 def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
-    """The fused gate/up GEMV at K = 4096 runs as a loader / consumer engine on LDS-DMA (csrc/gemv_engine.hip: one block per CU,
-    one loader wave, eight consumer waves, an 8 x 16 KiB ring); knob 11 = 0 selects gemv_q4_kernel<MODE_FFN> instead. Same
+    """The profiling build can run the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (csrc/gemv_engine.hip:
+    one block per CU, one loader wave, eight consumer waves, an 8 x 16 KiB ring; knob 11 = vmcnt lag, + 4 with the consumers'
+    next-slot prefetch); 0 is the product's gemv_q4_kernel<MODE_FFN>. Same
     arithmetic in the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split of quads over the CUs and
     the smallest covered width, every vmcnt lag, repeated launches (a race between the loader's fills and the consumers' reads
     would show as a run-to-run difference)."""
@@ -25,7 +26,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (0, 1, 2, 3):
+        for engine in (0, 1, 2, 3, 5):
             L.q4_set_gemv_early(11, engine)
             for rep in range(6):
                 dout = q4.DevBuf(nbytes=N * 2)
@@ -33,7 +34,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
                 q4.synchronize()
                 outs[(engine, rep)] = dout.get(np.float16, N).view(np.uint16).copy()
     finally:
-        L.q4_set_gemv_early(11, 1)
+        L.q4_set_gemv_early(11, 0)
     assert np.isfinite(outs[(0, 0)].view(np.float16).astype(np.float32)).all()
     for key, o in outs.items():
         assert np.array_equal(o, outs[(0, 0)]), key
