@@ -9,6 +9,9 @@ tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 out=gpurun_out/prof_$tag
 mkdir -p $out
+# a fresh box clocks up during its first seconds of work (the first trace of a call read 3 % slow once): warm it first
+timeout 120 python tools/prof_kernel.py 0 4000 > /dev/null 2>&1
+timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu --no-extra > /dev/null 2>&1
 for cfg in "7b 256" "13b 256" "7b 2048"; do
   set -- $cfg
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$1_$2 -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu --no-graphs --no-extra --model $1 --ntok $2 > $out/trace_$1_$2.log 2>&1
