@@ -37,9 +37,6 @@
 #ifndef Q4_W_AUX
 #define Q4_W_AUX 2   // buffer-load cache policy of the weight stream: nt (read once per token)
 #endif
-#ifndef Q4_DOT_MFMA
-#define Q4_DOT_MFMA 0  // 1 (experiment, `make mfma`): the per-lane dot products on the matrix pipe, see dot8_nibbles()
-#endif
 
 namespace q4 {
 
@@ -115,55 +112,13 @@ template <int MODE>
 struct ModeTraits { static constexpr int NMAT = (MODE == MODE_FFN) ? 2 : 1; };
 
 // permute 8 consecutive halves (x0..x7 as 4 dwords) into (x0,x4),(x1,x5),(x2,x6),(x3,x7)
-// (Q4_DOT_MFMA: (x0,x4),(x2,x6) | (x1,x5),(x3,x7) -- the even-nibble and the odd-nibble inputs as two aligned register pairs)
-constexpr int XE0 = 0, XO0 = Q4_DOT_MFMA ? 2 : 1, XE1 = Q4_DOT_MFMA ? 1 : 2, XO1 = 3;   // where (x0,x4), (x1,x5), (x2,x6), (x3,x7) sit
 __device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
     u32x4 o;
-    o[XE0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);   // lo16(v0) | lo16(v2)<<16
-    o[XO0] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);   // hi16(v0) | hi16(v2)<<16
-    o[XE1] = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);
-    o[XO1] = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
+    o[0] = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);   // lo16(v0) | lo16(v2)<<16
+    o[1] = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);   // hi16(v0) | hi16(v2)<<16
+    o[2] = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
     return o;
-}
-
-// 2^-20 * sum of the 32 (nibble x input) products of one uint4 unit: w = 4 weight dwords, X[d] = the permuted inputs of dword d.
-// Shipped form: a nibble left in place is an fp16 denormal, v_dot2c_f32_f16 multiplies it exactly; 1 shift + 4 v_and + 4 v_dot2c
-// per dword, two fp32 accumulators (even nibbles * 2^-24, odd nibbles * 2^-20).
-// Q4_DOT_MFMA = 1 (experiment): the same masked dwords go to v_mfma_f32_4x4x4_16b_f16 as A, the inputs as B. The instruction
-// multiplies, inside each group of four lanes, every lane's A row with every lane's B column; lane l's own dot product (4 halves
-// x 4 halves) is element l % 4 of its result -- a per-lane dot4 on the MATRIX pipe, two instructions per dword instead of four
-// on the VALU. Nothing about the data layout changes (this is not a GEMM: twelve of the sixteen products per lane group are
-// discarded). Denormal A inputs are multiplied exactly (tools/t_mfma.hip).
-typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float dot8_nibbles(const u32x4 w, const u32x4 (&X)[4], unsigned lane) {
-#if Q4_DOT_MFMA
-    f32x4 e4 = {0.f, 0.f, 0.f, 0.f}, o4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const unsigned ww = w[d];
-        const unsigned tt = ww >> 8;
-        const u32x2 ae = {ww & 0x000F000Fu, tt & 0x000F000Fu}, ao = {ww & 0x00F000F0u, tt & 0x00F000F0u};
-        const u32x2 be = {X[d][0], X[d][1]}, bo = {X[d][2], X[d][3]};
-        e4 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h4v, ae), __builtin_bit_cast(h4v, be), e4, 0, 0, 0);
-        o4 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h4v, ao), __builtin_bit_cast(h4v, bo), o4, 0, 0, 0);
-    }
-    const unsigned q = lane & 3u;
-    const float e = q == 0 ? e4[0] : q == 1 ? e4[1] : q == 2 ? e4[2] : e4[3];
-    const float o = q == 0 ? o4[0] : q == 1 ? o4[1] : q == 2 ? o4[2] : o4[3];
-    return __builtin_fmaf(e, 16.f, o);
-#else
-    float acc_e = 0.f, acc_o = 0.f;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const unsigned ww = w[d];
-        const unsigned tt = ww >> 8;
-        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[d][XE0]), acc_e, false);   // (n0,n4) * 2^-24
-        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[d][XO0]), acc_o, false);   // (n1,n5) * 2^-20
-        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][XE1]), acc_e, false);   // (n2,n6)
-        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][XO1]), acc_o, false);   // (n3,n7)
-    }
-    return __builtin_fmaf(acc_e, 16.f, acc_o);          // 2^-20 * sum q x
-#endif
 }
 
 // vdst/src half exchange (v_permlane32_swap): returns a' + b' where lanes 0-31 = a[l] + a[l+32],
@@ -407,7 +362,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             // x-only term of the zero point: sum of the 32 inputs of uint4 j (4 consecutive units = one lane quad)
             float cb = 0.f;
 #pragma unroll
-            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4 == 0 ? XE0 : d4 == 1 ? XO0 : d4 == 2 ? XE1 : XO1]), ones, cb, false);
+            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
             cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum
             const unsigned j = u >> 2, d = u & 3u;
             if (u < NUNITS) {
@@ -478,8 +433,19 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
                     const u32x4 w = W[m][s][c];
                     t = as_f(((w[0] ^ w[1] ^ w[2] ^ w[3]) & 0x007FFFFFu) | 0x3F000000u) + as_f(X[s & 3][c & 3] & 0x3FFFFFFFu);
                 } else {
+                    const u32x4 w = W[m][s][c];
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d];
+                        const unsigned tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[d][0]), acc_e, false);   // (n0,n4) * 2^-24
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[d][1]), acc_o, false);   // (n1,n5) * 2^-20
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][2]), acc_e, false);   // (n2,n6)
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][3]), acc_o, false);   // (n3,n7)
+                    }
                     const float zf = (float)((ZW[m][s][c] >> zsh) & 0xFu);
-                    t = dot8_nibbles(W[m][s][c], X, lane);           // 2^-20 * sum q x
+                    t = __builtin_fmaf(acc_e, 16.f, acc_o);          // 2^-20 * sum q x
                     t = __builtin_fmaf(zf, corr, t);                 // - z * 2^-20 * sum x
                 }
                 // idle tail lanes (j >= pw4) multiply re-read weights by the zero padding of xs/sx: exactly 0
