@@ -256,6 +256,19 @@ def main():
                                     "graph over the ring of the layers' weights, kernel + boundary",
                     "isolated_ring_us": kernels[kb[0][0]]["us"],
                     "per_kernel": per_kernel}
+        # what else bounds the kernel: the committed SQ counters of the same launch (tools/profile_sq.sh). The int4 dequant-dot is
+        # VALU work: the pipes are busy for most of the launch, which is why bytes-in-flight experiments never paid
+        for tag in ("r04",):
+            sq_path = os.path.join(ROOT, "profiles", "%s_sq_counters_gate_up.json" % tag)
+            if os.path.exists(sq_path) and args.model == "7b":
+                sq = json.load(open(sq_path))
+                clock_ghz = 2.1       # shader clock under this load (s_memtime against the 100 MHz wall clock, tools/timeline.py)
+                busy_us = sq.get("valu_busy_cycles_per_simd", 0.0) / (clock_ghz * 1e3)
+                roofline["valu"] = {"instructions_per_launch": sq.get("SQ_INSTS_VALU"), "instructions_per_wave": sq.get("valu_instructions_per_wave"),
+                                    "cycles_per_instruction": sq.get("cycles_per_valu_instruction"),
+                                    "busy_cycles_per_simd": sq.get("valu_busy_cycles_per_simd"), "busy_us_at_2.1GHz": round(busy_us, 2),
+                                    "busy_fraction_of_launch": round(busy_us / dom["us"], 3),
+                                    "source": "profiles/%s_sq_counters_gate_up.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ...)" % tag}
         kernels["in_network_us"] = in_network
         int4_bytes = sum(kb[k][1] for k in (0, 2, 3, 4))
         int4_us = sum(kernels[kb[k][0]]["us"] for k in (0, 2, 3, 4))

@@ -20,6 +20,14 @@ using namespace q4;
 
 namespace {
 
+// profiling build: wall-clock stamps (100 MHz) of the kernel's phases, written by thread 0 into the sampler's `indices` scratch
+// (which nothing else uses) as 64-bit words: tools/sampler_kernel_time.py prints them
+#ifdef Q4_PROFILING
+#define SMP_STAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(indices)[k] = wall_clock64(); } while (0)
+#else
+#define SMP_STAMP(k) do { } while (0)
+#endif
+
 constexpr int SMP_T = 1024, SMP_W = 16, SMP_E = 32;   // threads, waves, register-resident elements per thread
 
 __device__ __forceinline__ float block_tree_sum(float v, float* red) {   // red: 16 floats
@@ -58,7 +66,9 @@ __device__ unsigned softmax_phase(q4_half* __restrict__ logits, int size, float 
 #pragma unroll
         for (int k = 0; k < SMP_E; k++)
             if (tid + k * SMP_T < size) max_val = fmaxf(max_val, v[k]);
+        SMP_STAMP(1);
         max_val = block_tree_max(max_val, red);
+        SMP_STAMP(2);
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < SMP_E; k++)
@@ -67,7 +77,9 @@ __device__ unsigned softmax_phase(q4_half* __restrict__ logits, int size, float 
                 v[k] = round_h(e);
                 sum += e;
             }
+        SMP_STAMP(3);
         sum = block_tree_sum(sum, red);
+        SMP_STAMP(4);
 #pragma unroll
         for (int k = 0; k < SMP_E; k++) {
             const int t = tid + k * SMP_T;
@@ -303,7 +315,9 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
     unsigned* cnt = onchip ? dyn + SMP_T * SMP_E : dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) hit = 0x7fffffff;
+    SMP_STAMP(0);
     const unsigned top = softmax_phase(logits, n, temperature, indices, red);    // sampler.h:53
+    SMP_STAMP(5);
     const int E = (n + SMP_T - 1) / SMP_T;
     int token = 0;
     if (do_sort && top != 0 && h2f((uint16_t)(top >> 16)) >= threshold) {
@@ -431,6 +445,7 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
         scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
         if (tid == 0) token = v1[hit == 0x7fffffff ? n - 1 : hit];
     }
+    SMP_STAMP(6);
     if (x_next != nullptr) {                                 // (uniform: a kernel argument)
         if (tid == 0) s_token = token;
         __syncthreads();

@@ -11,6 +11,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llama_cu_awq_amd import api, synth   # noqa: E402
 
+PROF = os.environ.get("Q4_PROFILING_BUILD", "") == "1"     # then the kernel stamps its phases into the sampler's indices scratch
+
 path = "/tmp/llama2_q4_synth_v32k_seed5.bin"
 if not os.path.exists(path):
     synth.write_model(path, "v32k", seed=5)
@@ -45,4 +47,13 @@ for name, logits in rows.items():
                 us[what] = (time.perf_counter() - t0) / n * 1e6
         us = us["copy+sample"] - us["copy"]
         print("%-10s temperature %.2f top-p %.1f: %.1f us per sample() call (last token %d)" % (name, temp, topp, us, t.token(t.pos())), flush=True)
+        if PROF:
+            class SamplerStruct(C.Structure):
+                _fields_ = [("vocab_size", C.c_int), ("indices", C.c_void_p)]
+            ind = C.cast(t.sampler, C.POINTER(SamplerStruct)).contents.indices
+            st = np.empty(8, dtype=np.uint64)
+            api.check(L.q4_memcpy_d2h(st.ctypes.data, ind, st.nbytes))
+            d = (st[1:7].astype(np.int64) - st[0:6].astype(np.int64)) * 0.01
+            print("           phases (us): load + divide + local max %.2f | block max %.2f | exp + local sum %.2f | block sum %.2f | "
+                  "normalise + store + top %.2f | search / sort / scan %.2f" % tuple(d), flush=True)
         t.close()
