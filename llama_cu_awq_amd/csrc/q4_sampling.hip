@@ -294,14 +294,62 @@ __device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot
     __syncthreads();
 }
 
+// Vocabularies of up to 32 x 1024 entries, a multiple of 8: the softmax's elementwise work (a division, an exponential) and its
+// sum spread over SMX_B = 16 CUs -- on one CU it is 17 us of the sampling launch (tools/sampler_kernel_time.py stamps) -- in the
+// SAME arithmetic order as softmax_phase, whose canonical sum is: thread t of 1024 adds its elements t + 1024 k for ascending k, a
+// wave tree over each 64 threads, a 16-lane DPP tree over the 16 wave totals. Block b of this launch is "wave b": its lanes are the
+// virtual threads 64 b .. 64 b + 63. Every block finds the global maximum by itself (the whole vocabulary is 64 KB of L2 hits: no
+// grid-wide exchange; max_k half(l_k / T) = half(max_k l_k / T) since the map is monotone), real thread (j, l) computes the
+// elements k = 2 j, 2 j + 1 of virtual thread l, the fp32 exponentials meet in LDS, wave 0 adds each virtual thread's 32 values in
+// order, and the wave tree's result goes to wave_total[b]. The fp16-rounded exponentials go to a scratch array (`logits` is still
+// being read by slower blocks); topp_sample_kernel<true> normalises them with the 16-lane tree over wave_total.
+constexpr int SMX_B = 16;
+__global__ void __launch_bounds__(SMP_T) softmax_spread_kernel(const q4_half* __restrict__ logits, int n, float temperature,
+                                                             uint16_t* __restrict__ e16, float* __restrict__ wave_total) {
+    __shared__ float red[16];
+    __shared__ float es[SMP_E][64];
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, b = blockIdx.x;
+    // global maximum of the raw logits, 16-byte loads (n % 8 == 0)
+    float m = -3.402823466e+38f;
+    for (int u = tid; u < (n >> 3); u += SMP_T) {
+        const u32x4 q = reinterpret_cast<const u32x4*>(logits)[u];
+#pragma unroll
+        for (int d = 0; d < 4; d++) { const h2 p = as_h2(q[d]); m = fmaxf(m, fmaxf((float)p.x, (float)p.y)); }
+    }
+    m = block_tree_max(m, red);
+    const float max_val = round_h(m / temperature);                // = max over t of half(logit_t / T), gpu_kernels.h:511,522-531
+    const int E = (n + SMP_T - 1) / SMP_T;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        const int k = 2 * j + kk, t = b * 64 + lane + k * SMP_T;
+        float e = 0.f;
+        if (k < E && t < n) {
+            float val = h2f(logits[t]);
+            val /= temperature;                                    // :511
+            e = expf(round_h(val) - max_val);                      // :536
+            e16[t] = f2h(e);
+        }
+        es[k][lane] = e;                                           // (+0 for the entries past the vocabulary: x + 0 = x)
+    }
+    __syncthreads();
+    if (j == 0) {
+        float sum = 0.0f;
+        for (int k = 0; k < E; k++) sum += es[k][lane];            // the virtual thread's own order
+        sum = wave_sum(sum);
+        if (lane == 0) wave_total[b] = sum;
+    }
+}
+
+// PRE: the exponentials and the wave totals come from softmax_spread_kernel (e16 = k0, wave_total); this launch normalises and searches.
 // coins != nullptr (the step is part of a captured graph): the coin of this step is coins[position] -- the host draws the
 // xorshift stream (sampler.h:31-40) ahead of the replay and leaves the values in a pinned ring, so the launch carries no
 // per-step argument -- else `coin`. x_next != nullptr (several steps per replay): the sampled token's embedding row becomes the
 // next step's residual stream right here, like argmax_kernel does for greedy steps.
+template <bool PRE>
 __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int n, float temperature, int do_sort,
                                                           float coin, const float* coins, float topp, int* indices, uint16_t* k0, int* v0,
                                                           uint16_t* k1, int* v1, int* result, volatile int* pPos,
-                                                          int* pPosGpu, q4_half* x_next, const q4_half* table, int dim) {
+                                                          int* pPosGpu, q4_half* x_next, const q4_half* table, int dim, const float* wave_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned dyn[];   // [32768] sort buffer (on-chip path) + [4096] counters
     __shared__ float red[16];
     __shared__ unsigned wtot[16];
@@ -316,7 +364,38 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) hit = 0x7fffffff;
     SMP_STAMP(0);
-    const unsigned top = softmax_phase(logits, n, temperature, indices, red);    // sampler.h:53
+    unsigned top = 0;
+    if (PRE) {
+        // normalise (gpu_kernels.h:549): p = half(half(e) / sum), sum = the 16-lane tree over the wave totals. Elementwise and
+        // order-free, so 8 consecutive entries per thread and 16-byte loads / stores
+        const float sum = row16_sum(wave_total[lane & 15]);
+        for (int u = tid; u < (n >> 3); u += SMP_T) {
+            const u32x4 q = reinterpret_cast<const u32x4*>(k0)[u];
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint16_t p0 = f2h(h2f((uint16_t)(q[d] & 0xffffu)) / sum), p1 = f2h(h2f((uint16_t)(q[d] >> 16)) / sum);
+                o[d] = (unsigned)p0 | ((unsigned)p1 << 16);
+                const unsigned t0 = (unsigned)u * 8u + 2u * d;
+                const unsigned key0 = ((unsigned)p0 << 16) | (0xFFFFu - t0), key1 = ((unsigned)p1 << 16) | (0xFFFFu - (t0 + 1u));
+                top = key0 > top ? key0 : top;
+                top = key1 > top ? key1 : top;
+            }
+            reinterpret_cast<u32x4*>(logits)[u] = o;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(top, off); top = o > top ? o : top; }
+        unsigned* redu = reinterpret_cast<unsigned*>(red);
+        __syncthreads();
+        if (lane == 0) redu[wave] = top;
+        __syncthreads();
+        top = redu[0];
+#pragma unroll
+        for (int w = 1; w < SMP_W; w++) top = redu[w] > top ? redu[w] : top;
+        __syncthreads();
+    } else {
+        top = softmax_phase(logits, n, temperature, indices, red);    // sampler.h:53
+    }
     SMP_STAMP(5);
     const int E = (n + SMP_T - 1) / SMP_T;
     int token = 0;
@@ -468,6 +547,10 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
 // scratch and LDS opt-in of the sampling launch: outside any stream capture (hipMalloc / hipFuncSetAttribute are not capturable)
 extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_prepare(Sampler* sampler) {
     const int n = sampler->vocab_size;
+    if (sampler->temp_storage_bytes_scan == 0) {                                    // (the scan scratch of sampler.h:72-76: 16 wave totals here)
+        Q4_HIP(hipMalloc(&sampler->tempStorage_scan, 256));
+        sampler->temp_storage_bytes_scan = 256;
+    }
     if (sampler->temp_storage_bytes_sort == 0) {                                    // sampler.h:62-66 (lazy scratch)
         const size_t bytes = 2 * ((size_t)n * sizeof(uint16_t) + 256) + 2 * ((size_t)n * sizeof(int) + 256);
         Q4_HIP(hipMalloc(&sampler->tempStorage_sort, bytes));
@@ -475,7 +558,8 @@ extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_prepare(Samp
     }
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
+        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
+        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
         lds_opt_in = true;
     }
     return Q4_OK;
@@ -492,8 +576,15 @@ extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampl
     uint16_t* k0 = (uint16_t*)base; uint16_t* k1 = (uint16_t*)(base + kb);
     int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
     const size_t smem = (n <= SMP_T * SMP_E ? (size_t)SMP_T * SMP_E * 4 : 0) + 256 * SMP_W * 4;
-    Q4_LAUNCH(topp_sample_kernel, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, coin, coins, sampler->topp,
-              sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, x_next, table, dim);   // :53-80
+    float* wave_total = (float*)sampler->tempStorage_scan;
+    if (n <= SMP_T * SMP_E && (n & 7) == 0) {      // the softmax over 16 CUs, then normalise + search on one
+        Q4_LAUNCH(softmax_spread_kernel, dim3(SMX_B), dim3(SMP_T), 0, s->logits, n, sampler->temperature, k0, wave_total);
+        Q4_LAUNCH(topp_sample_kernel<true>, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, coin, coins, sampler->topp,
+                  sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, x_next, table, dim, wave_total);
+    } else {
+        Q4_LAUNCH(topp_sample_kernel<false>, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, coin, coins, sampler->topp,
+                  sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, x_next, table, dim, wave_total);   // :53-80
+    }
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
