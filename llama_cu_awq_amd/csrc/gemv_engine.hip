@@ -2,8 +2,8 @@
 // loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic
 // as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit
 // (tests/prof_cases.py compares the two forms). The shipped library does not contain it: measured on MI355X (DESIGN.md section 9
-// item 12, profiles/r04_engine_records.txt) it lands the 47 MB in 7.0 us at 7.5 TB/s and still ends where the shipped kernel
-// ends -- 9.69-9.73 against 9.72-9.76 us per launch by rocprofv3 in one call, 955.7 against 961.3 tokens/s in the token loop --
+// item 12, profiles/r04_engine_records.txt) it lands the 47 MB in 7.0 us at 7.5 TB/s and still ends AFTER the shipped kernel
+// -- 9.76 against 9.51-9.65 us per launch by rocprofv3 in one call, 937 against 951 tokens/s as the token loop's gate/up launch --
 // because the int4 dequant-dot is VALU work, not bandwidth.
 //
 // Idea: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded by its VGPRs, no
