@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Step A of the loader / consumer engine (csrc/gemv_engine.hip) against the shipped gate/up kernel, in ONE process:
 bit equality of q4_ffn_matvec_silu and of the norm-fused launch on the 7B geometry, then per-launch time (HIP events
-and inside a hipGraph) and tokens/s for engine = 0 (gemv_q4_kernel) and 1..3 (vmcnt lag).  tools/engine_check.py [model]"""
+and inside a hipGraph) and tokens/s for engine = 0 (gemv_q4_kernel), 1..3 (vmcnt lag) and 5, 6 (lag 1, 2 with the consumers' next-slot
+prefetch).  ENGINE_VARIANTS=1,5 tools/engine_check.py [model]"""
 import ctypes as C
 import os
 import sys
@@ -19,7 +20,7 @@ s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 ENGINE = 11
-VARIANTS = [int(v) for v in os.environ.get("ENGINE_VARIANTS", "2,3,6,7,10,11").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("ENGINE_VARIANTS", "1,2,3,5").split(",")]
 
 # ---- 1. the public op, no norm -------------------------------------------------------------------------
 rng = np.random.default_rng(7)
