@@ -314,9 +314,12 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
 }
 #undef ENG_STAMP
 
+#include "gemv_strip.h"   // the second form: no loader wave, every wave streams its own units (knob values 8..14)
+
 // the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
 // ... on a stream that may use every CU (one 147 KiB block per CU: on a CU-masked stream the blocks would queue behind each other)
 bool ffn_engine_covers(const GemvArgs& a) {
+    if (ffn_strip_covers(a)) return true;
     return g_engine >= 1 && g_engine <= 7 && g_engine != 4 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
            divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count() && stream_cu_count() == cu_count();
 }
@@ -348,6 +351,7 @@ static int launch_engine_lag(const GemvArgs& a) {
 }
 
 int launch_ffn_engine(const GemvArgs& a) {
+    if (ffn_strip_covers(a)) return launch_ffn_strip(a);
     const bool norm = a.rms_w != nullptr;
     if (a.dbg) return norm ? launch_engine_lag<true, true>(a) : launch_engine_lag<false, true>(a);
     return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);

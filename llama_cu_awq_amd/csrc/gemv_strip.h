@@ -1,0 +1,252 @@
+// gemv_strip.h -- EXPERIMENT, profiling build only, included by gemv_engine.hip (q4_set_gemv_early(11, 8..14)): the fused gate/up GEMV
+// at K = 4096 as "strips". NO loader wave: one 16-wave block per CU owns a contiguous range of columns; every wave streams its OWN
+// units -- unit u = wv + 16 i of the block's (column, matrix) pairs, 2 KiB each -- with `buffer_load_dwordx4 ... nt lds` into a
+// private ring of D 1 KiB pieces, waits for its oldest piece with vmcnt (a wave's loads return in order), reads it back with
+// ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD (the loader /
+// consumer engine had two), x staged once per CU by waves 0..7 and held in 32 registers by every wave. Same arithmetic in the same
+// order as gemv_q4_kernel<MODE_FFN>, bit for bit (tests/prof_cases.py).
+//   MODE 0 ("plain"): a wave sends its whole ring at entry and re-issues an entry when it has read it: D pieces in flight per wave.
+//   MODE 1 ("paced"): at most TWO pieces of a wave in flight whatever the depth of its ring (32 KiB per CU is what the CU's memory
+//          pipe takes without stalling the issue; more in flight measured slower): an issue is
+//          preceded by vmcnt(1). The waves that do not stage x fill their rings during the x chain, one piece per piece landed;
+//          the x chain synchronises through LDS counters (a wave stalled in vmcnt must not hold a hardware barrier up).
+//   MODE 2: MODE 1 with the dealing order rotated by eight waves: the waves that do not stage x take the longer share.
+#pragma once
+
+constexpr int STRIP_WAVES = 16, STRIP_NCMAX = 56;
+template <int D>
+struct StripLds {
+    static constexpr unsigned RING = 0;                                      // [16 waves][D] x 1 KiB
+    static constexpr unsigned SIDE_S_BYTES = 4096u;                          // per matrix: 56 columns x 32 groups x 2 B = 3584
+    static constexpr unsigned SIDE_S = RING + STRIP_WAVES * D * 1024u;
+    static constexpr unsigned SIDE_Z_BYTES = 1024u;                          // per matrix: 56 columns x 4 words x 4 B = 896
+    static constexpr unsigned SIDE_Z = SIDE_S + 2 * SIDE_S_BYTES;
+    static constexpr unsigned XS = SIDE_Z + 2 * SIDE_Z_BYTES;                // [2][4][64] x 16 B permuted x
+    static constexpr unsigned SX = XS + 8192u;                               // [2][64] -(sum of the 32 x) * 2^-20
+    static constexpr unsigned PART = SX + 512u;                              // [512] rmsnorm chunk partials
+    static constexpr unsigned TOT = PART + 2048u;                            // [NCMAX][2] column totals
+    static constexpr unsigned STAMP = TOT + 512u;                            // [64] wall-clock stamps (STAMPS builds)
+    static constexpr unsigned FLAGS = STAMP + 512u;                          // paced builds: sum-of-squares arrivals, staged arrivals, fail
+    static constexpr unsigned BYTES = FLAGS + 64u;
+};
+enum { SF_SS = 0, SF_STAGED = 1, SF_FAIL = 2 };
+__device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// stamps (tools/timeline_strip.py; kept in LDS and written out at the end: a global store would count in vmcnt): [0] wave 0 entry,
+// [1] its x landed, [2] sum of squares exchanged, [3] x staged, [4 + i] its unit i multiplied, [12] its totals written, [13] outputs
+// stored; [16 + w] wave w entry, [32 + w] wave w's first piece read, [48 + w] wave w's last unit multiplied
+#define SSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
+template <bool NORM, int D, int MODE, bool STAMPS>
+__global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const GemvArgs a, const unsigned cbase, const unsigned crem) {
+    static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's two pieces are compile-time constants");
+    constexpr bool PACED = MODE >= 1;
+    using L = StripLds<D>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned c0 = blockIdx.x * cbase + (blockIdx.x < crem ? blockIdx.x : crem);
+    const int nc = (int)(cbase + (blockIdx.x < crem ? 1u : 0u));
+    const int mat = wave & 1;
+    const int wv = MODE == 2 ? ((wave + 8) & 15) : wave;   // position in the dealing order
+    const int nu = (2 * nc - wv + 15) >> 4;            // this wave's units: u = wv + 16 i, column c0 + u / 2, matrix u % 2
+    const int npieces = 2 * nu;
+    const unsigned voff = lane * 16u;
+    const bool stager = wave < 8;
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + L::STAMP);
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + L::FLAGS);
+    SSTAMP(16 + wave);
+    if (wave == 0) SSTAMP(0);
+    if (PACED && wave == 15 && lane < 16u) flags[lane] = 0u;
+
+    // ---- what this wave will wait for first, in the order it is needed: side data, x, then its ring of weights
+    if (wave < 10) {                                   // scales (4 KiB) and zeros (1 KiB) of the block's columns, per matrix
+        const int m = wave >= 5, p = wave - 5 * m;
+        if (p < 4) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * 64u + p * 1024u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rz, c0 * 16u);
+        }
+    }
+    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
+    if (stager) {                                      // asm loads: hipcc must not count them (it cannot see the DMA pieces behind them)
+        const u32x4* px = reinterpret_cast<const u32x4*>(a.x) + tid;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
+        if (NORM) {
+            const u32x4* pw = reinterpret_cast<const u32x4*>(a.rms_w) + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
+        }
+    }
+    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order); flags are zero
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[mat].w, 0, a.N * a.pw4 * 16, 0x00020000);
+    const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
+    const unsigned soff0 = (c0 + ((unsigned)wv >> 1)) * 2048u;            // piece k = 2 i + ks: soff0 + i * 16384 + ks * 1024
+    auto issue = [&](int k) { dma_piece(ring + (unsigned)(k & (D - 1)) * 1024u, voff, rw, soff0 + (unsigned)(k >> 1) * 16384u + (unsigned)(k & 1) * 1024u); };
+    constexpr int D0 = PACED ? 2 : D;                  // pieces a wave sends at entry
+    int I = npieces < D0 ? npieces : D0;               // pieces issued so far
+#pragma unroll
+    for (int k = 0; k < D0; k++)
+        if (k < npieces) issue(k);
+
+    // ---- x chain (gemv_q4_body's staging, one 8-half chunk per thread of waves 0..7)
+    u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
+    float* sx = reinterpret_cast<float*>(smem + L::SX);
+    float* part = reinterpret_cast<float*>(smem + L::PART);
+    float* tot = reinterpret_cast<float*>(smem + L::TOT);
+    if (stager || !PACED) {
+        if (npieces >= D0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xraw), "+v"(wraw) : "n"(D0) : "memory");   // all but the weight pieces
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xraw), "+v"(wraw) : : "memory");                            // (a narrow matrix: fewer were issued)
+    }
+    if (wave == 0) SSTAMP(1);
+    if (NORM) {
+        if (stager) part[tid] = sumsq8(xraw, 0.f);
+        if (!PACED) block_barrier_lds();
+        else if (stager) { lds_bump(&flags[SF_SS], lane); lds_wait_ge(&flags[SF_SS], 8u, &flags[SF_FAIL]); }
+        if (wave == 0) SSTAMP(2);
+    }
+    if (stager) {
+        float ss = 1.f;
+        if (NORM) ss = rms_scale_from_partials<512>(part, 512, a.K);
+        u32x4 v = xraw;
+        if (NORM) v = rms_apply8(v, wraw, ss);
+        const u32x4 pv = permute_x8(v);
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        float cb = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+        cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);   // quad sum: the 32 inputs of one uint4 unit
+        const unsigned j = tid >> 2, d = tid & 3u;
+        xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+        if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
+    }
+    if (!PACED) block_barrier_lds();                   // x staged; side data landed (its issuers passed the vmcnt wait above)
+    else {
+        if (stager) lds_bump(&flags[SF_STAGED], lane);                      // a wave's LDS operations execute in order: its writes are in front
+        else {
+            // the other eight waves fill their rings meanwhile, one piece for every piece that lands (never more than two in flight);
+            // waves 8 and 9 carry side pieces: theirs are older than their ring, so "at most one outstanding" covers them
+            bool told = wave >= 10;
+            while (I < npieces && I < D) {
+                wait_vmcnt<1>();
+                if (!told) { lds_bump(&flags[SF_STAGED], lane); told = true; }
+                issue(I);
+                I++;
+                if (lds_peek(&flags[SF_STAGED]) >= 10u) break;
+            }
+            if (!told) { wait_vmcnt<1>(); lds_bump(&flags[SF_STAGED], lane); }
+        }
+        lds_wait_ge(&flags[SF_STAGED], 10u, &flags[SF_FAIL]);
+    }
+    if (wave == 0) SSTAMP(3);
+    u32x4 X[2][4];
+    float corr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lane];
+        corr[ks] = sx[ks * 64 + lane];
+    }
+    const unsigned char* wbase = smem + ring + lane * 16u;
+    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wv >> 1) * 32u + (lane >> 2)) * 2u;   // + i * 8 columns * 64 B
+    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wv >> 1) * 4u + (lane >> 5)) * 4u;    // + i * 8 columns * 16 B
+    const unsigned zsh = ((lane >> 2) & 7u) * 4u;
+
+    for (int g4 = 0; g4 * 4 < nu; g4++) {
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = g4 * 4 + r;
+            if (i < nu) {
+                float c = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int j = 2 * i + ks;
+                    constexpr int DM1 = D - 1;
+                    const int e = (2 * r + ks) & DM1;                       // j % D (8 g4 is a multiple of D)
+                    if (!PACED) {
+                        if (j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();   // piece j has landed
+                    } else {
+                        if (I < npieces && I - j < D) { issue(I); I++; }    // at most one was in flight: now two; the entry's last reader was piece I - D < j
+                        if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();     // pieces < I - 1 have landed, and I >= j + 2
+                    }
+                    if (j == 0) SSTAMP(32 + wave);
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
+                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * 512u + ks * 32);
+                    const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * 128u + ks * 8);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
+                    if (!PACED && j + D < npieces) issue(j + D);
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d];
+                        const unsigned tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[ks][d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[ks][d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[ks][d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[ks][d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((zw >> zsh) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr[ks], t);
+                    c = __builtin_fmaf(h2f(sc), t, c);
+                }
+                cs[r] = c;
+                if (STAMPS) { asm volatile("" : "+v"(c)); if (wave == 0 && i < 8) SSTAMP(4 + i); if (i == nu - 1) SSTAMP(48 + wave); }
+            }
+        }
+        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit g4 * 4 + r
+        const int row = lane >> 4;
+        if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wv + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
+    }
+    if (wave == 0) SSTAMP(12);
+    block_barrier_lds();
+    if ((int)tid < nc) {
+        const float g = tot[2 * tid], u = tot[2 * tid + 1];
+        float val = g;
+        val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
+        val *= u;                                       // :272
+        a.out[0][c0 + tid] = (PACED && lds_peek(&flags[SF_FAIL]) != 0u) ? (uint16_t)0x7E00u : f2h(val);   // (NaN: a wait ran out)
+    }
+    if (STAMPS) {
+        if (wave == 0) SSTAMP(13);
+        block_barrier_lds();
+        if (a.dbg && tid < 64u) a.dbg[(size_t)blockIdx.x * 64 + tid] = st[tid];
+    }
+}
+#undef SSTAMP
+
+static bool ffn_strip_covers(const GemvArgs& a) {
+    const int nb = cu_count();
+    return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && a.K == 4096 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+           a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
+}
+template <bool NORM, int D, int MODE, bool STAMPS>
+static int launch_strip(const GemvArgs& a) {
+    static bool opted = false;
+    constexpr size_t smem = StripLds<D>::BYTES;
+    if (!opted) {
+        Q4_HIP(hipFuncSetAttribute((const void*)ffn_strip_kernel<NORM, D, MODE, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        opted = true;
+    }
+    const unsigned nb = (unsigned)cu_count();
+    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, a, (unsigned)a.N / nb, (unsigned)a.N % nb);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
+template <bool NORM, bool STAMPS>
+static int launch_strip_setting(const GemvArgs& a) {
+    switch (g_engine) {
+        case 8: return launch_strip<NORM, 2, 0, STAMPS>(a);
+        case 9: return launch_strip<NORM, 4, 0, STAMPS>(a);
+        case 10: return launch_strip<NORM, 8, 0, STAMPS>(a);
+        case 12: return launch_strip<NORM, 4, 1, STAMPS>(a);
+        case 13: return launch_strip<NORM, 8, 1, STAMPS>(a);
+        default: return launch_strip<NORM, 8, 2, STAMPS>(a);
+    }
+}
+static int launch_ffn_strip(const GemvArgs& a) {
+    const bool norm = a.rms_w != nullptr;
+    if (a.dbg) return norm ? launch_strip_setting<true, true>(a) : launch_strip_setting<false, true>(a);
+    return norm ? launch_strip_setting<true, false>(a) : launch_strip_setting<false, false>(a);
+}

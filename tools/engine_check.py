@@ -20,7 +20,7 @@ s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 ENGINE = 11
-VARIANTS = [int(v) for v in os.environ.get("ENGINE_VARIANTS", "1,2,3,5").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("ENGINE_VARIANTS", "1,8,9,10").split(",")]
 
 # ---- 1. the public op, no norm -------------------------------------------------------------------------
 rng = np.random.default_rng(7)
