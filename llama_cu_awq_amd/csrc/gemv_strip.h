@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const GemvA
                     if (!PACED) {
                         if (j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();   // piece j has landed
                     } else {
+                        if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();     // pieces < I - 1 have landed, and I >= j + 2: piece j has
                         if (I < npieces && I - j < D) { issue(I); I++; }    // at most one was in flight: now two; the entry's last reader was piece I - D < j
-                        if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();     // pieces < I - 1 have landed, and I >= j + 2
                     }
                     if (j == 0) SSTAMP(32 + wave);
                     const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
@@ -242,7 +242,7 @@ static int launch_strip_setting(const GemvArgs& a) {
         case 10: return launch_strip<NORM, 8, 0, STAMPS>(a);
         case 12: return launch_strip<NORM, 4, 1, STAMPS>(a);
         case 13: return launch_strip<NORM, 8, 1, STAMPS>(a);
-        default: return launch_strip<NORM, 8, 2, STAMPS>(a);
+        default: return launch_strip<NORM, 8, 2, STAMPS>(a);   // 14
     }
 }
 static int launch_ffn_strip(const GemvArgs& a) {

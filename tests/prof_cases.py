@@ -26,7 +26,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (0, 1, 2, 3, 5, 8, 9, 10):
+        for engine in (0, 1, 2, 3, 5, 8, 9, 10, 12, 13, 14):
             L.q4_set_gemv_early(11, engine)
             for rep in range(6):
                 dout = q4.DevBuf(nbytes=N * 2)

@@ -52,4 +52,19 @@ b = int(np.argmax(t[:, 13]))
 print("last block to finish: %d; wave 0 row:" % b, " ".join("%.2f" % x for x in us(t[b, 0:14])))
 print("  first piece per wave:", " ".join("%.2f" % x for x in us(t[b, 32:48])))
 print("  done per wave:       ", " ".join("%.2f" % x for x in us(t[b, 48:64])))
+end = us(t[:, 13])
+print("outputs stored by XCD (block % 8): " + " ".join("%.2f" % end[x::8].mean() for x in range(8)))
+print("slowest 12 blocks: " + " ".join("%d:%.2f" % (b, end[b]) for b in np.argsort(-end)[:12]))
+print("fastest 12 blocks: " + " ".join("%d:%.2f" % (b, end[b]) for b in np.argsort(end)[:12]))
+# a second launch: are the same blocks late?
+L.q4_set_gemv_early(11, setting)
+L.q4_set_debug_buffer(dbg.ptr)
+tr.bench_kernel(0, 33)
+api.synchronize()
+t2 = dbg.get(np.uint64)[: nb * 64].reshape(nb, 64).astype(np.int64)
+L.q4_set_debug_buffer(None)
+end2 = (t2[:, 13] - t2[:, 16:32].min()) * 0.01
+print("second launch (another layer's weights): outputs stored median %.2f max %.2f; correlation of the blocks' end times with the first: %.2f" % (
+    np.median(end2), end2.max(), np.corrcoef(end, end2)[0, 1]))
+print("  by XCD: " + " ".join("%.2f" % end2[x::8].mean() for x in range(8)))
 tr.close()
