@@ -37,7 +37,10 @@ __device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lg
 // stored; [16 + w] wave w entry, [32 + w] wave w's first piece read, [48 + w] wave w's last unit multiplied
 #define SSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
 template <bool NORM, int D, int MODE, bool STAMPS>
-__global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const GemvArgs a, const unsigned cbase, const unsigned crem) {
+__global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
+                                                                     const unsigned cbase, const unsigned crem, const GemvArgs a) {
+    // the scalars the entry needs come first: built with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of
+    // through a scalar load from the kernel-argument segment (tools/timeline_strip.py: "x landed")
     static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's two pieces are compile-time constants");
     constexpr bool PACED = MODE >= 1;
     using L = StripLds<D>;
@@ -58,7 +61,16 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const GemvA
     if (wave == 0) SSTAMP(0);
     if (PACED && wave == 15 && lane < 16u) flags[lane] = 0u;
 
-    // ---- what this wave will wait for first, in the order it is needed: side data, x, then its ring of weights
+    // ---- what this wave will wait for first: x (its address arrives in SGPRs when the build preloads kernel arguments), side data, then its ring
+    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
+    if (stager) {                                      // asm loads: hipcc must not count them (it cannot see the DMA pieces behind them)
+        const u32x4* px = arg_x + tid;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
+        if (NORM) {
+            const u32x4* pw = arg_rms + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
+        }
+    }
     if (wave < 10) {                                   // scales (4 KiB) and zeros (1 KiB) of the block's columns, per matrix
         const int m = wave >= 5, p = wave - 5 * m;
         if (p < 4) {
@@ -69,17 +81,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const GemvA
             dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rz, c0 * 16u);
         }
     }
-    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
-    if (stager) {                                      // asm loads: hipcc must not count them (it cannot see the DMA pieces behind them)
-        const u32x4* px = reinterpret_cast<const u32x4*>(a.x) + tid;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
-        if (NORM) {
-            const u32x4* pw = reinterpret_cast<const u32x4*>(a.rms_w) + tid;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
-        }
-    }
     block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order); flags are zero
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[mat].w, 0, a.N * a.pw4 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
     const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
     const unsigned soff0 = (c0 + ((unsigned)wv >> 1)) * 2048u;            // piece k = 2 i + ks: soff0 + i * 16384 + ks * 1024
     auto issue = [&](int k) { dma_piece(ring + (unsigned)(k & (D - 1)) * 1024u, voff, rw, soff0 + (unsigned)(k >> 1) * 16384u + (unsigned)(k & 1) * 1024u); };
@@ -230,7 +233,8 @@ static int launch_strip(const GemvArgs& a) {
         opted = true;
     }
     const unsigned nb = (unsigned)cu_count();
-    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, a, (unsigned)a.N / nb, (unsigned)a.N % nb);
+    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
+              (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / nb, (unsigned)a.N % nb, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
