@@ -30,12 +30,13 @@
 //            executed; the loader refills slot j % 8 when every read[w] >= j - 7 (a single running total would not do: the waves
 //            are not in lock step, four of them two slots ahead count like eight of them one slot ahead).
 //   consumer-only barriers of the x chain: one LDS counter each.
-#include "gemv_q4.h"
+#include "gemv_strip.h"   // the form that ships for wide matrices: no loader wave, every wave streams its own units (+ the LDS-DMA and LDS-flag helpers)
 
 namespace q4 {
 
-int g_engine = 0;   // 0: gemv_q4_kernel<MODE_FFN> everywhere (the product); 1..3: the engine with LAG = value where the shape is covered (1 measured best);
-                    // 5, 6 = LAG 1, 2 with the consumers' next-slot prefetch
+int g_engine = 0;   // 0: the product's choice (gemv_strip.h: strips for wide matrices, gemv_q4_kernel<MODE_FFN> otherwise). Profiling build: -1 = gemv_q4_kernel
+                    // always; 1..3: the loader / consumer engine with LAG = value where the shape is covered (1 measured best); 5, 6 = LAG 1, 2 with the
+                    // consumers' next-slot prefetch; 8..14: a strips variant
 
 #ifdef Q4_PROFILING
 
@@ -59,48 +60,6 @@ struct EngLds {
 };
 enum { F_LANDED = 0, F_BAR0 = 2, F_BAR1 = 3, F_BAR2 = 4, F_FAIL = 5, F_READ0 = 8 };   // [F_READ0 + w]: slots consumer wave w has read
 
-// one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
-// M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
-__device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Flag words in LDS. A wave's LDS operations execute in program order, so "write data, then bump the flag" and "see the flag, then
-// read data" need no hardware fence inside a workgroup; the relaxed forms + compiler barriers keep hipcc from re-ordering them AND
-// from attaching its own waits: for an acquire / release at workgroup scope it emits s_waitcnt vmcnt(0) here (it cannot see the
-// asm LDS-DMA pieces, but it counts the x loads at the kernel's entry), which would drain the loader's stream at every flag.
-__device__ __forceinline__ unsigned lds_peek(unsigned* p) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_post(unsigned* p, unsigned v, unsigned lane) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
-// Every wait is on a wave of the SAME block (all resident by construction: no scheduling order can wedge it), and still bounded
-// (~10 s): a wait that runs out -- a logic error, not a race -- raises the block's fail word, and the block then stores NaN, so the
-// failure is loud in every consumer of the result instead of a hung GPU or plausible garbage.
-constexpr unsigned ENG_SPIN_LIMIT = 1u << 27;
-__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target, unsigned* fail) {
-    unsigned v = lds_peek(p);
-    for (unsigned n = 0; v < target; n++) {
-        if (n >= ENG_SPIN_LIMIT || ((n & 1023u) == 1023u && lds_peek(fail) != 0u)) { lds_post(fail, 1u, 0u); break; }
-        __builtin_amdgcn_s_sleep(1);
-        v = lds_peek(p);
-    }
-    return v;
-}
 // the loader's wait for a ring slot: all ENG_CONSUMERS per-wave counts (one word each, lanes 0..7 read one apiece) >= target
 __device__ __forceinline__ void lds_wait_all_ge(unsigned* p, unsigned target, unsigned lane, unsigned* fail) {
     for (unsigned n = 0;; n++) {
@@ -314,8 +273,6 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
 }
 #undef ENG_STAMP
 
-#include "gemv_strip.h"   // the second form: no loader wave, every wave streams its own units (knob values 8..14)
-
 // the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
 // ... on a stream that may use every CU (one 147 KiB block per CU: on a CU-masked stream the blocks would queue behind each other)
 bool ffn_engine_covers(const GemvArgs& a) {
@@ -357,10 +314,10 @@ int launch_ffn_engine(const GemvArgs& a) {
     return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);
 }
 
-#else    // the shipped library: no engine
+#else    // the shipped library: strips where they pay, no loader / consumer engine
 
-bool ffn_engine_covers(const GemvArgs&) { return false; }
-int launch_ffn_engine(const GemvArgs&) { return Q4_ERR_UNSUPPORTED_SIZE; }
+bool ffn_engine_covers(const GemvArgs& a) { return ffn_strip_covers(a); }
+int launch_ffn_engine(const GemvArgs& a) { return launch_ffn_strip(a); }
 
 #endif
 

@@ -12,19 +12,67 @@
 //          the x chain synchronises through LDS counters (a wave stalled in vmcnt must not hold a hardware barrier up).
 //   MODE 2: MODE 1 with the dealing order rotated by eight waves: the waves that do not stage x take the longer share.
 #pragma once
+#include "gemv_q4.h"
+
+namespace q4 {
+
+// one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
+// M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
+__device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Flag words in LDS. A wave's LDS operations execute in program order, so "write data, then bump the flag" and "see the flag, then
+// read data" need no hardware fence inside a workgroup; the relaxed forms + compiler barriers keep hipcc from re-ordering them AND
+// from attaching its own waits: for an acquire / release at workgroup scope it emits s_waitcnt vmcnt(0) here (it cannot see the
+// asm LDS-DMA pieces, but it counts the x loads at the kernel's entry), which would drain the loader's stream at every flag.
+__device__ __forceinline__ unsigned lds_peek(unsigned* p) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_post(unsigned* p, unsigned v, unsigned lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// Every wait is on a wave of the SAME block (all resident by construction: no scheduling order can wedge it), and still bounded
+// (~10 s): a wait that runs out -- a logic error, not a race -- raises the block's fail word, and the block then stores NaN, so the
+// failure is loud in every consumer of the result instead of a hung GPU or plausible garbage.
+constexpr unsigned ENG_SPIN_LIMIT = 1u << 27;
+__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target, unsigned* fail) {
+    unsigned v = lds_peek(p);
+    for (unsigned n = 0; v < target; n++) {
+        if (n >= ENG_SPIN_LIMIT || ((n & 1023u) == 1023u && lds_peek(fail) != 0u)) { lds_post(fail, 1u, 0u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = lds_peek(p);
+    }
+    return v;
+}
 
 constexpr int STRIP_WAVES = 16, STRIP_NCMAX = 56;
-template <int D>
+// TS = k-slots of a column: 2 (K = 4096: two 1 KiB pieces) or 3 (K = 5120: two pieces and a half one, the shared half slot of gemv_q4.h)
+template <int D, int TS = 2>
 struct StripLds {
+    static constexpr unsigned NS_S = TS == 2 ? 4u : 5u, NS_Z = TS == 2 ? 1u : 2u;   // 1 KiB side pieces per matrix
     static constexpr unsigned RING = 0;                                      // [16 waves][D] x 1 KiB
-    static constexpr unsigned SIDE_S_BYTES = 4096u;                          // per matrix: 56 columns x 32 groups x 2 B = 3584
+    static constexpr unsigned SIDE_S_BYTES = NS_S * 1024u;                   // per matrix: 56 columns x 32 (40) groups x 2 B = 3584 (4480)
     static constexpr unsigned SIDE_S = RING + STRIP_WAVES * D * 1024u;
-    static constexpr unsigned SIDE_Z_BYTES = 1024u;                          // per matrix: 56 columns x 4 words x 4 B = 896
+    static constexpr unsigned SIDE_Z_BYTES = NS_Z * 1024u;                   // per matrix: 56 columns x 4 (5) words x 4 B = 896 (1120)
     static constexpr unsigned SIDE_Z = SIDE_S + 2 * SIDE_S_BYTES;
-    static constexpr unsigned XS = SIDE_Z + 2 * SIDE_Z_BYTES;                // [2][4][64] x 16 B permuted x
-    static constexpr unsigned SX = XS + 8192u;                               // [2][64] -(sum of the 32 x) * 2^-20
-    static constexpr unsigned PART = SX + 512u;                              // [512] rmsnorm chunk partials
-    static constexpr unsigned TOT = PART + 2048u;                            // [NCMAX][2] column totals
+    static constexpr unsigned XS = SIDE_Z + 2 * SIDE_Z_BYTES;                // [TS][4][64] x 16 B permuted x
+    static constexpr unsigned SX = XS + TS * 4096u;                          // [TS][64] -(sum of the 32 x) * 2^-20
+    static constexpr unsigned PART = SX + TS * 256u;                         // [TS * 256] rmsnorm chunk partials (zero past K / 8)
+    static constexpr unsigned TOT = PART + TS * 1024u;                       // [NCMAX][2] column totals
     static constexpr unsigned STAMP = TOT + 512u;                            // [64] wall-clock stamps (STAMPS builds)
     static constexpr unsigned FLAGS = STAMP + 512u;                          // paced builds: sum-of-squares arrivals, staged arrivals, fail
     static constexpr unsigned BYTES = FLAGS + 64u;
@@ -36,14 +84,18 @@ __device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lg
 // [1] its x landed, [2] sum of squares exchanged, [3] x staged, [4 + i] its unit i multiplied, [12] its totals written, [13] outputs
 // stored; [16 + w] wave w entry, [32 + w] wave w's first piece read, [48 + w] wave w's last unit multiplied
 #define SSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
-template <bool NORM, int D, int MODE, bool STAMPS>
+template <bool NORM, int D, int MODE, bool STAMPS, int TS = 2>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
                                                                      const unsigned cbase, const unsigned crem, const GemvArgs a) {
     // the scalars the entry needs come first: built with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of
     // through a scalar load from the kernel-argument segment (tools/timeline_strip.py: "x landed")
-    static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's two pieces are compile-time constants");
+    static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's pieces are compile-time constants");
+    static_assert(TS == 2 || (TS == 3 && MODE == 0 && D <= 4), "K = 5120: the plain form, 12 pieces per four units a multiple of the ring");
     constexpr bool PACED = MODE >= 1;
-    using L = StripLds<D>;
+    constexpr unsigned CB = TS == 2 ? 2048u : 2560u;   // bytes of a column
+    constexpr unsigned G = TS == 2 ? 32u : 40u, ZW = TS == 2 ? 4u : 5u;   // its quantisation groups (one fp16 scale each), its words of zero nibbles
+    constexpr int NSTAGE = TS == 2 ? 8 : 10;           // waves that stage x: one 8-half chunk per thread
+    using L = StripLds<D, TS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,9 +104,12 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
     const int mat = wave & 1;
     const int wv = MODE == 2 ? ((wave + 8) & 15) : wave;   // position in the dealing order
     const int nu = (2 * nc - wv + 15) >> 4;            // this wave's units: u = wv + 16 i, column c0 + u / 2, matrix u % 2
-    const int npieces = 2 * nu;
+    const int npieces = TS * nu;
     const unsigned voff = lane * 16u;
-    const bool stager = wave < 8;
+    const bool stager = wave < NSTAGE;
+    // K = 5120: a column's third piece is 512 bytes, 32 lanes. As in gemv_q4.h's shared half slot the lower half of the wave takes it
+    // for the first column of a pair (even), the upper half for the second (odd): the same lanes add the same terms
+    const bool upper = lane >= 32u;
     unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + L::STAMP);
     unsigned* flags = reinterpret_cast<unsigned*>(smem + L::FLAGS);
     SSTAMP(16 + wave);
@@ -71,26 +126,34 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
         }
     }
-    if (wave < 10) {                                   // scales (4 KiB) and zeros (1 KiB) of the block's columns, per matrix
-        const int m = wave >= 5, p = wave - 5 * m;
-        if (p < 4) {
+    constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);    // side pieces per matrix: scales (4 or 5 KiB) and zeros (1 or 2 KiB) of the block's columns
+    if (wave < 2 * NSIDE) {
+        const int m = wave >= NSIDE, p = wave - NSIDE * m;
+        if (p < (int)L::NS_S) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
-            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * 64u + p * 1024u);
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * (G * 2u) + p * 1024u);
         } else {
             const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
-            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rz, c0 * 16u);
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff, rz, c0 * (ZW * 4u) + (p - (int)L::NS_S) * 1024u);
         }
     }
     block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order); flags are zero
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
     const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
-    const unsigned soff0 = (c0 + ((unsigned)wv >> 1)) * 2048u;            // piece k = 2 i + ks: soff0 + i * 16384 + ks * 1024
-    auto issue = [&](int k) { dma_piece(ring + (unsigned)(k & (D - 1)) * 1024u, voff, rw, soff0 + (unsigned)(k >> 1) * 16384u + (unsigned)(k & 1) * 1024u); };
+    const unsigned soff0 = (c0 + ((unsigned)wv >> 1)) * CB;               // piece k = TS i + ks: soff0 + i * 8 columns + ks * 1024
+    const bool odd = ((c0 + ((unsigned)wv >> 1)) & 1u) != 0u;             // (a wave's columns are 8 apart: one parity)
+    const unsigned voff_half = (lane & 31u) * 16u;
+    auto issue2 = [&](int i, int ks) {                 // piece ks of unit i (ks a constant at every call site)
+        const unsigned dst = ring + (unsigned)((TS * i + ks) & (D - 1)) * 1024u, so = soff0 + (unsigned)i * (8u * CB) + (unsigned)ks * 1024u;
+        if (TS == 3 && ks == 2) { if (upper == odd) dma_piece(dst, voff_half, rw, so); }   // 32 lanes: the LDS address follows the LANE, not the offset
+        else dma_piece(dst, voff, rw, so);
+    };
+    auto issue = [&](int k) { static_assert(TS == 2 || !PACED, "linear piece numbers: two pieces per unit"); issue2(k >> 1, k & 1); };
     constexpr int D0 = PACED ? 2 : D;                  // pieces a wave sends at entry
     int I = npieces < D0 ? npieces : D0;               // pieces issued so far
 #pragma unroll
     for (int k = 0; k < D0; k++)
-        if (k < npieces) issue(k);
+        if (k < npieces) issue2(k / TS, k % TS);
 
     // ---- x chain (gemv_q4_body's staging, one 8-half chunk per thread of waves 0..7)
     u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
@@ -103,14 +166,14 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
     }
     if (wave == 0) SSTAMP(1);
     if (NORM) {
-        if (stager) part[tid] = sumsq8(xraw, 0.f);
+        if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;      // (K = 5120: entries 640 .. 767 are the zero padding of the canonical sum)
         if (!PACED) block_barrier_lds();
         else if (stager) { lds_bump(&flags[SF_SS], lane); lds_wait_ge(&flags[SF_SS], 8u, &flags[SF_FAIL]); }
         if (wave == 0) SSTAMP(2);
     }
     if (stager) {
         float ss = 1.f;
-        if (NORM) ss = rms_scale_from_partials<512>(part, 512, a.K);
+        if (NORM) ss = rms_scale_from_partials<TS * 256>(part, TS * 256, a.K);
         u32x4 v = xraw;
         if (NORM) v = rms_apply8(v, wraw, ss);
         const u32x4 pv = permute_x8(v);
@@ -142,17 +205,18 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
         lds_wait_ge(&flags[SF_STAGED], 10u, &flags[SF_FAIL]);
     }
     if (wave == 0) SSTAMP(3);
-    u32x4 X[2][4];
-    float corr[2];
+    u32x4 X[TS][4];
+    float corr[TS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int ks = 0; ks < TS; ks++) {
+        const unsigned lu = (TS == 3 && ks == 2) ? (lane & 31u) : lane;      // half slot: both halves of the wave hold units 0-31
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lane];
-        corr[ks] = sx[ks * 64 + lane];
+        for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lu];
+        corr[ks] = sx[ks * 64 + lu];
     }
     const unsigned char* wbase = smem + ring + lane * 16u;
-    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wv >> 1) * 32u + (lane >> 2)) * 2u;   // + i * 8 columns * 64 B
-    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wv >> 1) * 4u + (lane >> 5)) * 4u;    // + i * 8 columns * 16 B
+    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wv >> 1) * G + (lane >> 2)) * 2u;   // + i * 8 columns * 64 (80) B
+    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wv >> 1) * ZW + (lane >> 5)) * 4u;    // + i * 8 columns * 16 (20) B
     const unsigned zsh = ((lane >> 2) & 7u) * 4u;
 
     for (int g4 = 0; g4 * 4 < nu; g4++) {
@@ -163,10 +227,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
             if (i < nu) {
                 float c = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    const int j = 2 * i + ks;
+                for (int ks = 0; ks < TS; ks++) {
+                    const int j = TS * i + ks;
                     constexpr int DM1 = D - 1;
-                    const int e = (2 * r + ks) & DM1;                       // j % D (8 g4 is a multiple of D)
+                    const int e = (TS * r + ks) & DM1;                      // j % D (4 TS g4 is a multiple of D)
+                    const bool hs = TS == 3 && ks == 2;                     // the half slot
                     if (!PACED) {
                         if (j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();   // piece j has landed
                     } else {
@@ -175,10 +240,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     }
                     if (j == 0) SSTAMP(32 + wave);
                     const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
-                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * 512u + ks * 32);
-                    const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * 128u + ks * 8);
+                    // scale and zero word of this lane's group: 16 ks + lane / 4, in the half slot 32 + (lane % 32) / 4
+                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (8u * G * 2u) + (hs ? 64 - (int)(upper ? 16u : 0u) : ks * 32));
+                    const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (8u * ZW * 4u) + (hs ? 16 - (int)(upper ? 4u : 0u) : ks * 8));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
-                    if (!PACED && j + D < npieces) issue(j + D);
+                    if (!PACED && j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
                     float acc_e = 0.f, acc_o = 0.f;
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
@@ -192,7 +258,12 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     const float zf = (float)((zw >> zsh) & 0xFu);
                     float t = __builtin_fmaf(acc_e, 16.f, acc_o);
                     t = __builtin_fmaf(zf, corr[ks], t);
-                    c = __builtin_fmaf(h2f(sc), t, c);
+                    if (hs) {       // gemv_q4.h's half slot: a product and a sum (not an fma), only on the half of the wave that serves this column
+                        const float v = h2f(sc) * t;
+                        c += (upper == odd) ? v : 0.f;
+                    } else {
+                        c = __builtin_fmaf(h2f(sc), t, c);
+                    }
                 }
                 cs[r] = c;
                 if (STAMPS) { asm volatile("" : "+v"(c)); if (wave == 0 && i < 8) SSTAMP(4 + i); if (i == nu - 1) SSTAMP(48 + wave); }
@@ -219,38 +290,72 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
 }
 #undef SSTAMP
 
-static bool ffn_strip_covers(const GemvArgs& a) {
+// Shapes: K = 4096 (two 1 KiB pieces per column), 16 .. 56 columns per CU, on a stream that may use every CU (the blocks do not wait for
+// each other: on a CU-masked stream the form would be correct, only slow). g_engine: 0 = the product's choice -- strips from
+// STRIP_MIN_COLS columns per CU on, where the wave-owned kernel's grid needs a seventh row of blocks per CU and strips measure
+// faster (tools/sweep_strips.py, per launch in a graph: 12800 columns 11.83 -> 10.56 us, 13312 11.89 -> 10.96, the Mistral / Llama-3
+// hidden size 14336 12.4 -> 11.45, 885 -> 902 tokens/s on the Mistral-7B geometry; up to 48 columns per CU -- Llama-2-7B's 11008 is 43 --
+// the two are level and the wave-owned kernel stays) --; the profiling build also takes -1 = never, 8 .. 14 = this variant wherever
+// the shape is covered.
+constexpr int STRIP_MIN_COLS = 49;
+extern int g_engine;
+static inline bool strip_k5120(const GemvArgs& a) { return a.K == 5120 && a.pw4 == 160 && a.sh == 40 && a.pzh == 5; }
+static bool ffn_strip_shape(const GemvArgs& a) {
     const int nb = cu_count();
-    return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && a.K == 4096 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
-           a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
+    // K = 4096, or K = 5120 (13B) where the wave-owned kernel would run its shared half slot, whose arithmetic the strips repeat
+    const bool k = (a.K == 4096 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4) || (strip_k5120(a) && a.nslots == 3 && half_tail(a));
+    return k && a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
 }
-template <bool NORM, int D, int MODE, bool STAMPS>
+static bool ffn_strip_covers(const GemvArgs& a) {
+    if (g_engine == 0) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);
+#ifdef Q4_PROFILING
+    return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && ffn_strip_shape(a);
+#else
+    return false;
+#endif
+}
+template <bool NORM, int D, int MODE, bool STAMPS, int TS = 2>
 static int launch_strip(const GemvArgs& a) {
-    static bool opted = false;
-    constexpr size_t smem = StripLds<D>::BYTES;
-    if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)ffn_strip_kernel<NORM, D, MODE, STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        opted = true;
+    constexpr size_t smem = StripLds<D, TS>::BYTES;
+    if (smem > 64 * 1024) {    // (the product's D = 2 form needs 54 KiB: no opt-in, nothing that a graph capture could not record)
+        static bool opted = false;
+        if (!opted) {
+            Q4_HIP(hipFuncSetAttribute((const void*)ffn_strip_kernel<NORM, D, MODE, STAMPS, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            opted = true;
+        }
     }
     const unsigned nb = (unsigned)cu_count();
-    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
+    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS, TS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
               (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / nb, (unsigned)a.N % nb, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
+#ifdef Q4_PROFILING
 template <bool NORM, bool STAMPS>
 static int launch_strip_setting(const GemvArgs& a) {
     switch (g_engine) {
-        case 8: return launch_strip<NORM, 2, 0, STAMPS>(a);
         case 9: return launch_strip<NORM, 4, 0, STAMPS>(a);
         case 10: return launch_strip<NORM, 8, 0, STAMPS>(a);
         case 12: return launch_strip<NORM, 4, 1, STAMPS>(a);
         case 13: return launch_strip<NORM, 8, 1, STAMPS>(a);
-        default: return launch_strip<NORM, 8, 2, STAMPS>(a);   // 14
+        case 14: return launch_strip<NORM, 8, 2, STAMPS>(a);
+        default: return launch_strip<NORM, 2, 0, STAMPS>(a);   // 0 (the product's form), 8
     }
 }
 static int launch_ffn_strip(const GemvArgs& a) {
     const bool norm = a.rms_w != nullptr;
+    if (strip_k5120(a)) {
+        if (g_engine == 9) return norm ? launch_strip<true, 4, 0, false, 3>(a) : launch_strip<false, 4, 0, false, 3>(a);
+        return norm ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
+    }
     if (a.dbg) return norm ? launch_strip_setting<true, true>(a) : launch_strip_setting<false, true>(a);
     return norm ? launch_strip_setting<true, false>(a) : launch_strip_setting<false, false>(a);
 }
+#else
+static int launch_ffn_strip(const GemvArgs& a) {
+    if (strip_k5120(a)) return a.rms_w ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
+    return a.rms_w ? launch_strip<true, 2, 0, false>(a) : launch_strip<false, 2, 0, false>(a);
+}
+#endif
+
+}  // namespace q4

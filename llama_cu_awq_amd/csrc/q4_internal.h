@@ -100,6 +100,7 @@ extern int g_ao_guard;
 extern int g_ao_vslice;
 extern int g_multi_steps;
 extern int g_engine;        // gemv_engine.hip
+int down_strip_prepare();   // gemv_plain.hip (gemv_strip_down.h): LDS opt-in of the 13B down projection's strips kernel, outside any stream capture
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, q4_half* x_next, const q4_half* table, int dim);
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,

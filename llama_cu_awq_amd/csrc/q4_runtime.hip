@@ -332,6 +332,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     fclose(file);
     if (rc) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }
     if (!g_quiet) printf("done!\n");
+    if ((rc = down_strip_prepare())) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }   // (an attribute call: before any graph capture)
 
     // malloc_run_state :38-67. att holds n_heads*max(seq_len, dim) halves (the reference's n_heads*dim overflows
     // for seq_len > dim); this build's attention does not use it at all.

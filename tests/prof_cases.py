@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N", [11008, 14336, 1024 * 4 + 8, 4096])
 def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
-    """The profiling build can run the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (csrc/gemv_engine.hip:
-    one block per CU, one loader wave, eight consumer waves, an 8 x 16 KiB ring; knob 11 = vmcnt lag, + 4 with the consumers'
-    next-slot prefetch); 0 is the product's gemv_q4_kernel<MODE_FFN>. Same
-    arithmetic in the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split of quads over the CUs and
-    the smallest covered width, every vmcnt lag, repeated launches (a race between the loader's fills and the consumers' reads
-    would show as a run-to-run difference)."""
+    """The fused gate/up GEMV at K = 4096 has three forms (knob 11): -1 = gemv_q4_kernel<MODE_FFN> (the wave-owned kernel), 8 .. 14 = "strips"
+    (csrc/gemv_strip.h: sixteen self-loading waves per CU on LDS-DMA rings; ring depth 2 / 4 / 8, plain and paced issue), 1 .. 6 = the
+    loader / consumer engine (csrc/gemv_engine.hip: one loader wave, eight consumer waves, an 8 x 16 KiB ring; vmcnt lag, + 4 with the
+    consumers' next-slot prefetch); 0 = the product's choice (strips from 49 columns per CU on, i.e. for 14336 here). Same arithmetic in
+    the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split over the CUs and the smallest covered width,
+    repeated launches (a race between a fill and a read would show as a run-to-run difference)."""
     L = q4.lib()
     K = 4096
     x = rng.standard_normal(K).astype(np.float16)
@@ -26,7 +26,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (0, 1, 2, 3, 5, 8, 9, 10, 12, 13, 14):
+        for engine in (-1, 0, 1, 2, 3, 5, 8, 9, 10, 12, 13, 14):
             L.q4_set_gemv_early(11, engine)
             for rep in range(6):
                 dout = q4.DevBuf(nbytes=N * 2)
@@ -35,9 +35,65 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
                 outs[(engine, rep)] = dout.get(np.float16, N).view(np.uint16).copy()
     finally:
         L.q4_set_gemv_early(11, 0)
-    assert np.isfinite(outs[(0, 0)].view(np.float16).astype(np.float32)).all()
+    assert np.isfinite(outs[(-1, 0)].view(np.float16).astype(np.float32)).all()
     for key, o in outs.items():
-        assert np.array_equal(o, outs[(0, 0)]), key
+        assert np.array_equal(o, outs[(-1, 0)]), key
+
+
+@pytest.mark.parametrize("N", [13824, 13824 + 8, 12800, 5120])
+def test_gate_up_strips_at_k5120_equal_the_shared_half_slot_kernel(q4, rng, N):
+    """K = 5120 (13B): a column is two 1 KiB pieces and a half one. The strips form (csrc/gemv_strip.h, TS = 3) gives the half piece to the
+    lower half of the wave for even columns and to the upper half for odd ones and adds its term as a product and a sum -- the lanes and
+    the operations of gemv_q4.h's shared half slot -- so the two forms must agree bit for bit: knob 11 = -1 (wave-owned kernel), 0 (the
+    product's choice: strips from 49 columns per CU on), 8 / 9 (strips, ring depth 2 / 4, wherever the shape is covered)."""
+    L = q4.lib()
+    K = 5120
+    x = rng.standard_normal(K).astype(np.float16)
+    g, u = synth.random_qweight(rng, K, N), synth.random_qweight(rng, K, N)
+    dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
+    outs = {}
+    try:
+        for engine in (-1, 0, 8, 9):
+            L.q4_set_gemv_early(11, engine)
+            for rep in range(4):
+                dout = q4.DevBuf(nbytes=N * 2)
+                q4.ffn_matvec_silu(dout, dx, dg, du, K, N)
+                q4.synchronize()
+                outs[(engine, rep)] = dout.get(np.float16, N).view(np.uint16).copy()
+    finally:
+        L.q4_set_gemv_early(11, 0)
+    assert np.isfinite(outs[(-1, 0)].view(np.float16).astype(np.float32)).all()
+    for key, o in outs.items():
+        assert np.array_equal(o, outs[(-1, 0)]), key
+
+
+@pytest.mark.parametrize("N", [5120, 5120 + 8, 2048, 6144])
+@pytest.mark.parametrize("accum", [False, True])
+def test_down_projection_strips_equal_the_k_split_kernel(q4, rng, N, accum):
+    """K = 13824 (the 13B down projection): csrc/gemv_strip_down.h runs mat_vec_kernel_int4 as two ten-wave blocks per CU whose waves stream
+    (column, k-part) units through LDS-DMA rings; the parts, the shared last slot and the part-0-then-part-1 sum are gemv_q4.h's K-split
+    kernel's, so the two must agree bit for bit, with and without the residual add: knob 11 = -1 (K-split kernel) against 0 (the product:
+    strips), for the 13B width, a ragged split, the narrowest and the widest covered grid."""
+    L = q4.lib()
+    K = 13824
+    x = (rng.standard_normal(K) * 0.5).astype(np.float16)
+    w = synth.random_qweight(rng, K, N)
+    res = rng.standard_normal(N).astype(np.float16)
+    dw, dx = q4.DevQWeight(*w), q4.DevBuf(x)
+    outs = {}
+    try:
+        for engine in (-1, 0):
+            L.q4_set_gemv_early(11, engine)
+            for rep in range(4):
+                dout = q4.DevBuf(res)
+                q4.matmul_q4(dout, dx, dw, K, N, accum=accum)
+                q4.synchronize()
+                outs[(engine, rep)] = dout.get(np.float16, N).view(np.uint16).copy()
+    finally:
+        L.q4_set_gemv_early(11, 0)
+    assert np.isfinite(outs[(-1, 0)].view(np.float16).astype(np.float32)).all()
+    for key, o in outs.items():
+        assert np.array_equal(o, outs[(-1, 0)]), key
 
 
 @pytest.mark.parametrize("K,N,kind", [(4096, 4096, 0), (11008, 4096, 1), (13824, 5120, 1), (4096, 11008, 3), (5120, 13824, 3)])

@@ -136,6 +136,31 @@ def test_grouped_query_model_at_mistral_7b_geometry(q4, orc, observed):
     m.close()
 
 
+def test_mistral_geometry_fused_equals_unfused_bits(q4):
+    """hidden_dim 14336 runs the gate/up GEMV as strips (csrc/gemv_strip.h), with the rmsnorm fused into its x staging at fusion level 1
+    and behind a separate rmsnorm launch at level 0: the two launch sequences must leave identical logits (same canonical reductions,
+    same rounding points), as they do for the wave-owned kernels (test_forward_gpu::test_fused_equals_unfused_bits; level 3 sums an
+    attention output's positions in another fp32 order below bin 512 -- DESIGN.md section 3.2 -- and is held to the restatement by
+    test_grouped_query_model_at_mistral_7b_geometry)."""
+    L = q4.lib()
+    path = _model("mistral7b")
+    outs = []
+    try:
+        for fusion in (0, 1):
+            L.q4_set_fusion(fusion)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            for pos in range(6):
+                t.run_transformer(pos >= 2)
+            q4.synchronize()
+            outs.append(t.logits().copy())
+            t.close()
+    finally:
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
 def _kv_to_host(q4, t):
     cfg = t.config
     kv_dim = cfg.dim * cfg.n_kv_heads // cfg.n_heads
