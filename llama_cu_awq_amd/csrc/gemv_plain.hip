@@ -12,11 +12,12 @@ int launch_gemv_plain(const GemvArgs& a, int cols, int waves) {
         const int sh = divUp(b.ku, 64);                        // up to 8 slots (K <= 32768, Llama-2-70B / CodeLlama-34B down projections)
         // a k-part whose last slot holds at most 32 units shares it between the columns of a pair (13B: 216 = 3 x 64 + 24)
         if (g_half_tail && g_ksplit != 4 && b.ku - (sh - 1) * 64 <= 32) {
-            if (down_strip_covers(b)) return launch_down_strip(b);   // the same arithmetic, every CU the same bytes (13B: 9.83 -> 8.64 us per launch)
+            if (down_strip_covers(b, true)) return launch_down_strip<4, true>(b);   // the same arithmetic, every CU the same bytes (13B: 9.83 -> 8.64 us per launch)
 #define Q4_KSH(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 2, true>(b, waves);
             Q4_KSH(2) Q4_KSH(3) Q4_KSH(4) Q4_KSH(5) Q4_KSH(6) Q4_KSH(7) Q4_KSH(8)
 #undef Q4_KSH
         }
+        if (g_ksplit != 4 && down_strip_covers(b, false)) return launch_down_strip<3, false>(b);
 #define Q4_KS(S) if (sh == S) return launch_one<MODE_PLAIN, S, 4, false, 0, 2>(b, waves);
         Q4_KS(1) Q4_KS(2) Q4_KS(3) Q4_KS(4) Q4_KS(5) Q4_KS(6) Q4_KS(7) Q4_KS(8)
 #undef Q4_KS

@@ -15,7 +15,8 @@
 
 namespace q4 {
 
-constexpr int SD_WAVES = 16, SD_NCMAX = 24, SD_ROWS = 7;   // 7 rows of 64 uint4 units: K <= 14336
+constexpr int SD_WAVES = 16, SD_NCMAX = 24, SD_ROWS = 7;
+   // 7 rows of 64 uint4 units: K <= 14336
 struct StripDownLds {
     static constexpr unsigned RING = 0;                                 // [16 waves][2] x 1 KiB
     static constexpr unsigned SIDE_S = RING + SD_WAVES * 2048u;         // 6 KiB: 24 columns x 112 groups x 2 B = 5376 (13B: 20 x 216)
@@ -26,12 +27,14 @@ struct StripDownLds {
     static constexpr unsigned BYTES = TOT + SD_NCMAX * 8u;
 };
 
-template <int SH>   // slots of a k-part, the last one shared (at most 32 units)
+// SH = slots of a k-part; SHARED: the last one holds at most 32 units and is shared between the columns of a pair (gemv_q4.h's HALF form; 13B),
+// else it is an ordinary slot whose lanes past the part's end add nothing (7B: 172 = 64 + 64 + 44)
+template <int SH, bool SHARED>
 __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* __restrict__ arg_x, const void* arg_w, const unsigned wbytes, const unsigned cbase,
                                                                  const unsigned crem, const GemvArgs a) {
     using L = StripDownLds;
     constexpr int PPU = SH;                            // DMA pieces per unit
-    static_assert(SH >= 2 && SH <= 4 && (PPU % 2) == 0, "ring entry of a piece = its slot's parity");
+    static_assert(SH >= 2 && SH <= 4, "a unit is SH pieces; ring entry of piece ks of unit i = (SH i + ks) % 2, i a constant at every site");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,9 +75,11 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
     const unsigned tail = ku - (unsigned)(SH - 1) * 64u;                 // uint4 units in the shared slot (<= 32)
     auto issue2 = [&](int i, int ks) {
         const unsigned col = col0 + 8u * (unsigned)i;
-        const unsigned dst = ring + (unsigned)(ks & 1) * 1024u, so = col * colbytes + (ubase + 64u * (unsigned)ks) * 16u;
-        if (ks == SH - 1) { if (upper == ((col & 1u) != 0u) && lu < tail && ubase + 64u * (unsigned)ks + lu < uend) dma_piece(dst, lu * 16u, rw, so); }
-        else dma_piece(dst, voff, rw, so);
+        const unsigned dst = ring + (unsigned)((PPU * i + ks) & 1) * 1024u, so = col * colbytes + (ubase + 64u * (unsigned)ks) * 16u;
+        if (ks == SH - 1) {
+            if (SHARED) { if (upper == ((col & 1u) != 0u) && lu < tail && ubase + 64u * (unsigned)ks + lu < uend) dma_piece(dst, lu * 16u, rw, so); }
+            else { if (lane < tail && ubase + 64u * (unsigned)ks + lane < uend) dma_piece(dst, voff, rw, so); }
+        } else dma_piece(dst, voff, rw, so);
     };
 #pragma unroll
     for (int k = 0; k < 2; k++)
@@ -120,12 +125,12 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
 #pragma unroll
             for (int ks = 0; ks < SH; ks++) {
                 const int j = PPU * i + ks;
-                const bool hs = ks == SH - 1;
+                const bool last = ks == SH - 1, hs = SHARED && last;
                 if (j + 2 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();        // piece j has landed
                 const unsigned unit = ubase + 64u * (unsigned)ks + (hs ? lu : lane);   // the uint4 unit this lane multiplies
-                const bool live = !hs || (upper == odd && lu < tail && unit < uend);
+                const bool live = !last || (SHARED ? (upper == odd && lu < tail && unit < uend) : (lane < tail && unit < uend));
                 const unsigned uj = unit < uend ? unit : uend - 1u;
-                const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + (ks & 1) * 1024);
+                const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + ((PPU * i + ks) & 1) * 1024);
                 const uint16_t sc = *reinterpret_cast<const uint16_t*>(sside + (lc * (unsigned)a.sh + (uj >> 2)) * 2u);
                 const unsigned zw = *reinterpret_cast<const unsigned*>(zside + (lc * (unsigned)a.pzh + (uj >> 5)) * 4u);
                 const unsigned xrow = ((uj >> 6) << 8) + (uj & 63u);
@@ -152,6 +157,9 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
                 if (hs) {           // the shared slot: a product and a sum, only on the half of the wave (and the lanes) that hold this column's units
                     const float v = h2f(sc) * t;
                     c += live ? v : 0.f;
+                } else if (last) {  // an ordinary last slot: its lanes past the part's end multiply zero inputs in gemv_q4.h, fma(s, 0, c) = c
+                    const float f = __builtin_fmaf(h2f(sc), t, c);
+                    c = live ? f : c;
                 } else {
                     c = __builtin_fmaf(h2f(sc), t, c);
                 }
@@ -175,28 +183,33 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
     }
 }
 
-// the shape: the K-split kernel's shared-slot form with four slots per part (12544 < K <= 14336 with a last slot of at most 32 units: Llama-2-13B's
-// 13824), no KV addressing, on a stream that may use every CU; at least eight columns per block
-static bool down_strip_covers(const GemvArgs& a) {
-    if (g_engine != 0 && g_engine != 8) return false;
+// the shapes: the K-split kernel (two k-parts, ku uint4 each) with up to four slots per part and at most seven 64-unit rows of x (K <= 14336), no KV
+// addressing, on a stream that may use every CU; 8 .. 24 columns per block. Llama-2-13B: K = 13824, four slots, the last shared (24 units): 9.83 ->
+// 8.64 us per launch, the product's choice. Llama-2-7B: K = 11008, three slots, the last an ordinary one of 44 units: bit-identical as well, and
+// SLOWER than the K-split kernel's 512 blocks = exactly two per CU (962 -> 936 tokens/s): only under the profiling build's knob 11 = 8.
+static bool down_strip_covers(const GemvArgs& a, bool shared) {
+    if (g_engine != 8 && !(g_engine == 0 && shared)) return false;
     const int nb = cu_count();
     const int sh = divUp(a.ku, 64);
-    return a.nslots >= 5 && sh == 4 && a.ku - (sh - 1) * 64 <= 32 && a.ku * 2 >= a.pw4 && divUp(a.pw4, 64) <= SD_ROWS && a.loff == -1 && a.rms_w == nullptr &&
+    const bool shape = shared ? (sh == 4 && a.ku - (sh - 1) * 64 <= 32) : (sh == 3 && a.ku - (sh - 1) * 64 > 32);
+    return a.nslots >= 5 && shape && a.ku * 2 >= a.pw4 && divUp(a.pw4, 64) <= SD_ROWS && a.loff == -1 && a.rms_w == nullptr &&
            a.N / nb >= 8 && divUp(a.N, nb) <= SD_NCMAX && g_ablate == 0 && stream_cu_count() == nb;
 }
 // 70 KiB of LDS: the opt-in is not a stream operation -- build_transformer makes it for the model (q4_runtime.hip), a stand-alone call at its first launch
 int down_strip_prepare() {
     static bool opted = false;
     if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)down_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripDownLds::BYTES));
+        Q4_HIP(hipFuncSetAttribute((const void*)down_strip_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripDownLds::BYTES));
+        Q4_HIP(hipFuncSetAttribute((const void*)down_strip_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripDownLds::BYTES));
         opted = true;
     }
     return Q4_OK;
 }
+template <int SH, bool SHARED>
 static int launch_down_strip(const GemvArgs& a) {
     { const int rc = down_strip_prepare(); if (rc) return rc; }
     const unsigned blocks = (unsigned)cu_count();
-    Q4_LAUNCH((down_strip_kernel<4>), dim3(blocks), dim3(SD_WAVES * 64), StripDownLds::BYTES, reinterpret_cast<const u32x4*>(a.x), (const void*)a.m[0].w,
+    Q4_LAUNCH((down_strip_kernel<SH, SHARED>), dim3(blocks), dim3(SD_WAVES * 64), StripDownLds::BYTES, reinterpret_cast<const u32x4*>(a.x), (const void*)a.m[0].w,
               (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / blocks, (unsigned)a.N % blocks, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;

@@ -67,22 +67,23 @@ def test_gate_up_strips_at_k5120_equal_the_shared_half_slot_kernel(q4, rng, N):
         assert np.array_equal(o, outs[(-1, 0)]), key
 
 
-@pytest.mark.parametrize("N", [5120, 5120 + 8, 2048, 6144])
+@pytest.mark.parametrize("K,N", [(13824, 5120), (13824, 5120 + 8), (13824, 2048), (13824, 6144), (11008, 4096), (11008, 4096 + 8), (11008, 2048), (11008, 6144)])
 @pytest.mark.parametrize("accum", [False, True])
-def test_down_projection_strips_equal_the_k_split_kernel(q4, rng, N, accum):
-    """K = 13824 (the 13B down projection): csrc/gemv_strip_down.h runs mat_vec_kernel_int4 as two ten-wave blocks per CU whose waves stream
-    (column, k-part) units through LDS-DMA rings; the parts, the shared last slot and the part-0-then-part-1 sum are gemv_q4.h's K-split
-    kernel's, so the two must agree bit for bit, with and without the residual add: knob 11 = -1 (K-split kernel) against 0 (the product:
-    strips), for the 13B width, a ragged split, the narrowest and the widest covered grid."""
+def test_down_projection_strips_equal_the_k_split_kernel(q4, rng, K, N, accum):
+    """The down projections (13B: K = 13824, four slots per k-part, the last shared between the columns of a pair; 7B: K = 11008, three slots,
+    an ordinary last one): csrc/gemv_strip_down.h runs mat_vec_kernel_int4 as one sixteen-wave block per CU whose waves stream (column, k-part)
+    units through LDS-DMA rings; the parts, the last slot's lanes and the part-0-then-part-1 sum are gemv_q4.h's K-split kernel's, so the two
+    must agree bit for bit, with and without the residual add: knob 11 = -1 (K-split kernel) against 0 (the product: strips at K = 13824, where
+    they are faster; the K-split kernel at K = 11008, where they are not) and 8 (strips wherever the shape is covered), for the model's width, a
+    ragged split, the narrowest and a wide covered grid."""
     L = q4.lib()
-    K = 13824
     x = (rng.standard_normal(K) * 0.5).astype(np.float16)
     w = synth.random_qweight(rng, K, N)
     res = rng.standard_normal(N).astype(np.float16)
     dw, dx = q4.DevQWeight(*w), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (-1, 0):
+        for engine in (-1, 0, 8):
             L.q4_set_gemv_early(11, engine)
             for rep in range(4):
                 dout = q4.DevBuf(res)
