@@ -1,10 +1,12 @@
-// gemv_engine.hip -- EXPERIMENT, profiling build only (q4_set_gemv_early(11, lag)): the fused gate/up GEMV at K = 4096 as a
-// loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic
-// as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit
-// (tests/prof_cases.py compares the two forms). The shipped library does not contain it: measured on MI355X (DESIGN.md section 9
-// item 12, profiles/r04_engine_records.txt) it lands the 47 MB in 7.0 us at 7.5 TB/s and still ends AFTER the shipped kernel
-// -- 9.76 against 9.51-9.65 us per launch by rocprofv3 in one call, 937 against 951 tokens/s as the token loop's gate/up launch --
-// because the int4 dequant-dot is VALU work, not bandwidth.
+// gemv_engine.hip -- the gate/up launch's other forms. In the product: the dispatch to "strips" (gemv_strip.h, the form that ships for wide
+// matrices: ffn_engine_covers / launch_ffn_engine, called by launch_gemv_ffn). In the profiling build also an EXPERIMENT
+// (q4_set_gemv_early(11, 1..6)): the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows
+// "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel +
+// ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit (tests/prof_cases.py compares the forms). The shipped library does
+// not contain the engine: measured on MI355X (profiles/r04_engine_records.txt) it lands the 47 MB in
+// 7.0 us at 7.5 TB/s and still ends AFTER the wave-owned kernel -- 9.76 against 9.51-9.65 us per launch by rocprofv3 in one call, 937
+// against 951 tokens/s as the token loop's gate/up launch -- its two consumer waves per SIMD do not keep up with the dequant (the strips
+// form, four self-loading waves per SIMD, does).
 //
 // Idea: in gemv_q4.h the wave that loads a weight also multiplies it, so the depth of the prefetch is bounded by its VGPRs, no
 // weight request goes out before the x chain of its block has been scheduled around, and every block re-stages x. Here one block

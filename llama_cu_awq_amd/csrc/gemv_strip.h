@@ -1,10 +1,11 @@
-// gemv_strip.h -- EXPERIMENT, profiling build only, included by gemv_engine.hip (q4_set_gemv_early(11, 8..14)): the fused gate/up GEMV
-// at K = 4096 as "strips". NO loader wave: one 16-wave block per CU owns a contiguous range of columns; every wave streams its OWN
-// units -- unit u = wv + 16 i of the block's (column, matrix) pairs, 2 KiB each -- with `buffer_load_dwordx4 ... nt lds` into a
-// private ring of D 1 KiB pieces, waits for its oldest piece with vmcnt (a wave's loads return in order), reads it back with
-// ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD (the loader /
-// consumer engine had two), x staged once per CU by waves 0..7 and held in 32 registers by every wave. Same arithmetic in the same
-// order as gemv_q4_kernel<MODE_FFN>, bit for bit (tests/prof_cases.py).
+// gemv_strip.h -- "strips": the fused gate/up GEMV (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275) on LDS-DMA rings. Ships
+// for wide matrices (ffn_strip_covers below); the profiling build runs every variant anywhere the shape is covered
+// (q4_set_gemv_early(11, 8..14); -1 = the wave-owned kernel always). NO loader wave: one 16-wave block per CU owns a contiguous range of columns;
+// every wave streams its OWN units -- unit u = wv + 16 i of the block's (column, matrix) pairs, 2 KiB each at K = 4096, 2.5 KiB at K = 5120 -- with
+// `buffer_load_dwordx4 ... nt lds` into a private ring of D 1 KiB pieces, waits for its oldest piece with vmcnt (a wave's loads return in order),
+// reads it back with ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD (the loader /
+// consumer engine of gemv_engine.hip had two), x staged once per CU by waves 0..7 (0..9) and held in 32 (48) registers by every wave. Same arithmetic
+// in the same order as gemv_q4_kernel<MODE_FFN>, bit for bit (tests/prof_cases.py).
 //   MODE 0 ("plain"): a wave sends its whole ring at entry and re-issues an entry when it has read it: D pieces in flight per wave.
 //   MODE 1 ("paced"): at most TWO pieces of a wave in flight whatever the depth of its ring (32 KiB per CU is what the CU's memory
 //          pipe takes without stalling the issue; more in flight measured slower): an issue is
