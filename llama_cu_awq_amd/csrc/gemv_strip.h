@@ -308,7 +308,7 @@ static bool ffn_strip_shape(const GemvArgs& a) {
     return k && a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
 }
 static bool ffn_strip_covers(const GemvArgs& a) {
-    if (g_engine == 0) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);
+    if (g_engine == 0 || g_engine == 15) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);   // (15: profiling, the product's gate/up choice without the down-projection strips)
 #ifdef Q4_PROFILING
     return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && ffn_strip_shape(a);
 #else

@@ -186,10 +186,17 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
 // the shapes: the K-split kernel (two k-parts, ku uint4 each) with up to four slots per part and at most seven 64-unit rows of x (K <= 14336), no KV
 // addressing, on a stream that may use every CU; 8 .. 24 columns per block. Llama-2-13B: K = 13824, four slots, the last shared (24 units): 9.83 ->
 // 8.64 us per launch, the product's choice. Llama-2-7B: K = 11008, three slots, the last an ordinary one of 44 units: bit-identical as well, and
-// SLOWER than the K-split kernel's 512 blocks = exactly two per CU (962 -> 936 tokens/s): only under the profiling build's knob 11 = 8.
+// SLOWER than the K-split kernel's 512 blocks = exactly two per CU (962 -> 936 tokens/s): only under the profiling build's knob 11 = 8
+// (which forces strips wherever the shape is covered).
 static bool down_strip_covers(const GemvArgs& a, bool shared) {
-    if (g_engine != 8 && !(g_engine == 0 && shared)) return false;
     const int nb = cu_count();
+    if (g_engine == 0) {
+        // the product's choice: where the K-split kernel's grid (8 columns per block) leaves the CUs uneven -- 13B: 640 blocks = 2.5 per CU, the launch
+        // pays for three; strips 536 -> 546 tokens/s. Where it divides evenly the K-split kernel is faster (Mistral geometry, K = 14336, 512 blocks:
+        // strips 899 -> 890 tokens/s; Llama-2-7B 962 -> 936)
+        const int blocks = divUp(a.N, 8), rem = blocks % nb;
+        if (!shared || rem == 0 || rem * 10 > nb * 6) return false;
+    } else if (g_engine != 8) return false;
     const int sh = divUp(a.ku, 64);
     const bool shape = shared ? (sh == 4 && a.ku - (sh - 1) * 64 <= 32) : (sh == 3 && a.ku - (sh - 1) * 64 > 32);
     return a.nslots >= 5 && shape && a.ku * 2 >= a.pw4 && divUp(a.pw4, 64) <= SD_ROWS && a.loff == -1 && a.rms_w == nullptr &&
