@@ -117,7 +117,10 @@ const char* q4_status_string(int status) {
 }
 const char* q4_last_error(void) { return g_last_error; }
 
-int q4_set_device(int device) { Q4_HIP(hipSetDevice(device)); return Q4_OK; }
+int q4_set_device(int device) {
+    Q4_HIP(hipSetDevice(device));
+    return down_strip_prepare();   // LDS opt-in of a kernel the public matmul may launch: an attribute call, made before any stream capture can begin
+}
 int q4_stream_create(q4_stream_t* out) {
     hipStream_t s;
     Q4_HIP(hipStreamCreate(&s));
