@@ -213,8 +213,9 @@ def main():
             else:   # o-proj QWeight + residual in/out + the K and V rows of positions 0..pos of every kv head + q + output
                 avg_pos_ = p0_ + 1.5
                 nb_ = kb[4][1] + int((avg_pos_ + 1) * 2 * kv_dim * 2) + 2 * cfg.dim * 2
-            if cls == 32:       # two launches of this class per token (final rmsnorm, classifier): price the pair
-                a_ = 2.0 * a_
+            if cls == 32:       # final rmsnorm + classifier: one launch where the classifier runs as strips with the norm inside (csrc/gemv_strip_cls.h),
+                if n_ >= 8:     # else two launches per token (4 steps timed): price the pair
+                    a_ = 2.0 * a_
                 nb_ += 3 * cfg.dim * 2
             per_kernel[nm] = {"hip_event_us": round(a_, 3), "bytes": nb_, "GBps": round(nb_ / a_ / 1e3, 1),
                               "frac": round(nb_ / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_, "first_position": p0_}
@@ -230,7 +231,7 @@ def main():
                 tj = tj_all.get("0", tj_all)
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
-                            "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": "gemv_f16_kernel<",
+                            "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
                             kb[0][0]: ("gemv_q4_kernel<2,", "ffn_strip_kernel<")}
                 for nm_, pre_ in prefixes.items():
                     ratios = [e_["traffic_over_algorithmic"] for k_, e_ in tj_all.get("%s_n%d" % (args.model, ntok), {}).items()

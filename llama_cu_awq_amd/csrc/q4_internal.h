@@ -100,6 +100,8 @@ extern int g_ao_guard;
 extern int g_ao_vslice;
 extern int g_multi_steps;
 extern int g_engine;        // gemv_engine.hip
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab);   // q4_kernels.hip
+int cls_strip_prepare();    // q4_kernels.hip (gemv_strip_cls.h): the same for the classifier's strips kernel
 int down_strip_prepare();   // gemv_plain.hip (gemv_strip_down.h): LDS opt-in of the 13B down projection's strips kernel, outside any stream capture
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)
 int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, q4_half* x_next, const q4_half* table, int dim);

@@ -3,7 +3,7 @@
 // fp16->fp32 copy; plus the C-ABI launchers of include/llama2_q4.h for every kernel.
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include "gemv_q4.h"
+#include "gemv_strip_cls.h"   // (gemv_q4.h, the LDS-DMA helpers) + the classifier as strips
 #include "attention.h"
 
 namespace q4 {
@@ -311,6 +311,7 @@ int q4_matmul_f16(q4_half* xout, const q4_half* x, const q4_half* w, int n, int 
     if ((n & 7) || (d & 7)) return Q4_ERR_UNSUPPORTED_SIZE;                         // llama2_q4.cu:215
     if (w_row_stride == -1) w_row_stride = n;                                       // :220
     if (w_row_stride & 7) return Q4_ERR_UNSUPPORTED_SIZE;
+    if (cls_strip_covers(n, d, batch, w_row_stride, alpha)) return launch_cls_strip(xout, x, nullptr, w, n, d);   // the classifier's shape: same bits, streamed through LDS-DMA rings
     constexpr int ROWS = 2, WAVES = 4;
     dim3 grid(divUp(d, ROWS * WAVES), batch);
     if (n <= 2048)
@@ -496,3 +497,12 @@ int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pP
 }
 }  // namespace q4
 
+// final rmsnorm + classifier (llama2_q4.cu:336, 339) as ONE launch where the strips form covers the shape: the norm is computed once per CU inside it and x
+// itself is left un-normalised (nothing reads it afterwards: the next step's embedding overwrites it); elsewhere the two launches of the reference
+namespace q4 {
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab) {
+    if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab);
+    const int rc = q4_rmsnorm(x, x, rms_w, dim);
+    return rc ? rc : q4_matmul_f16(logits, x, wcls, dim, vocab, 1, 0, 0, 0, -1, 1.0f);
+}
+}  // namespace q4

@@ -119,7 +119,9 @@ const char* q4_last_error(void) { return g_last_error; }
 
 int q4_set_device(int device) {
     Q4_HIP(hipSetDevice(device));
-    return down_strip_prepare();   // LDS opt-in of a kernel the public matmul may launch: an attribute call, made before any stream capture can begin
+    // LDS opt-ins of kernels the public matmuls may launch: attribute calls, made before any stream capture can begin
+    const int rc = down_strip_prepare();
+    return rc ? rc : cls_strip_prepare();
 }
 int q4_stream_create(q4_stream_t* out) {
     hipStream_t s;
@@ -335,7 +337,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     fclose(file);
     if (rc) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }
     if (!g_quiet) printf("done!\n");
-    if ((rc = down_strip_prepare())) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }   // (an attribute call: before any graph capture)
+    if ((rc = down_strip_prepare()) || (rc = cls_strip_prepare())) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }   // (an attribute call: before any graph capture)
 
     // malloc_run_state :38-67. att holds n_heads*max(seq_len, dim) halves (the reference's n_heads*dim overflows
     // for seq_len > dim); this build's attention does not use it at all.
@@ -537,8 +539,12 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
         }
         Q4_UNLESS(16, q4_matmul_q4(s->x, s->hb, &L->wq_down, hidden_dim, dim, 1, -1, nullptr));        // :332
     }
-    Q4_UNLESS(32, q4_rmsnorm(x, x, w->rms_final_weight, dim));                                         // :336
-    Q4_UNLESS(32, q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));  // :339
+    if (g_fusion >= 1) {      // one launch where the classifier runs as strips (gemv_strip_cls.h): the final norm inside its x staging
+        Q4_UNLESS(32, classifier_with_final_norm(s->logits, x, w->rms_final_weight, w->wcls, p->dim, p->vocab_size));
+    } else {
+        Q4_UNLESS(32, q4_rmsnorm(x, x, w->rms_final_weight, dim));                                         // :336
+        Q4_UNLESS(32, q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));  // :339
+    }
     return Q4_OK;
 }
 

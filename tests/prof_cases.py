@@ -97,6 +97,31 @@ def test_down_projection_strips_equal_the_k_split_kernel(q4, rng, K, N, accum):
         assert np.array_equal(o, outs[(-1, 0)]), key
 
 
+@pytest.mark.parametrize("n,d", [(4096, 32000), (5120, 32000), (4096, 32008), (5120, 16384), (4096, 128256)])
+def test_classifier_strips_equal_gemv_f16_kernel(q4, rng, n, d):
+    """The fp16 classifier GEMV as strips (csrc/gemv_strip_cls.h: one 16-wave block per CU, every wave streams whole vocabulary rows through its
+    LDS-DMA ring) repeats gemv_f16_kernel's per-lane sums and its wave reduction: bit equality, knob 11 = -1 (gemv_f16_kernel) against 0 (the
+    product: strips), at the Llama-2 sizes, a ragged split of rows, the narrowest covered matrix and the Llama-3 vocabulary."""
+    L = q4.lib()
+    w = (rng.standard_normal(n * d) * 0.02).astype(np.float16)
+    x = rng.standard_normal(n).astype(np.float16)
+    dw, dx = q4.DevBuf(w), q4.DevBuf(x)
+    outs = {}
+    try:
+        for engine in (-1, 0):
+            L.q4_set_gemv_early(11, engine)
+            for rep in range(3):
+                do = q4.DevBuf(nbytes=d * 2)
+                q4.matmul(do, dx, dw, n, d)
+                q4.synchronize()
+                outs[(engine, rep)] = do.get(np.float16, d).view(np.uint16).copy()
+    finally:
+        L.q4_set_gemv_early(11, 0)
+    assert np.isfinite(outs[(-1, 0)].view(np.float16).astype(np.float32)).all()
+    for key, o in outs.items():
+        assert np.array_equal(o, outs[(-1, 0)]), key
+
+
 @pytest.mark.parametrize("K,N,kind", [(4096, 4096, 0), (11008, 4096, 1), (13824, 5120, 1), (4096, 11008, 3), (5120, 13824, 3)])
 def test_early_bird_issue_order_is_bit_neutral(q4, rng, K, N, kind):
     """The early-bird issue order (first block per CU sends its weight loads before the staging completes) only moves

@@ -22,7 +22,9 @@ def test_rmsnorm(q4, orc, rng, size):
     assert_close_f16(dx.get(np.float16, size), ref, what="rmsnorm in place")
 
 
-@pytest.mark.parametrize("n,d", [(4096, 32000), (5120, 1000), (256, 512), (2048, 64)])
+# (4096, 32000), (5120, 32008) and (4096, 16384) run as strips (csrc/gemv_strip_cls.h: n = 4096 / 5120, at least 64 rows per CU; 32008 = a ragged split
+# of rows over the CUs), the others as gemv_f16_kernel
+@pytest.mark.parametrize("n,d", [(4096, 32000), (5120, 1000), (256, 512), (2048, 64), (5120, 32008), (4096, 16384), (4096, 16376)])
 def test_matmul_f16(q4, orc, rng, n, d):
     w = (rng.standard_normal(n * d) * 0.02).astype(np.float16)
     x = rng.standard_normal(n).astype(np.float16)

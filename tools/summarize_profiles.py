@@ -67,7 +67,7 @@ def algorithmic(kernel, model, ntok):
         return 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2
     if kernel.startswith("gemv_q4_kernel<0") or kernel.startswith("down_strip_kernel"):
         return qweight_bytes(h, d) + h * 2 + 2 * d * 2
-    if kernel.startswith("gemv_f16_kernel"):
+    if kernel.startswith("gemv_f16_kernel") or kernel.startswith("cls_strip_kernel"):
         return v * d * 2 + d * 2 + v * 2
     if kernel.startswith("attention_oproj_kernel"):
         # o-proj QWeight + residual in / out + q + attention output + K and V rows of the context, averaged over the context
