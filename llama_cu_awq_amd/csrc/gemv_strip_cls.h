@@ -8,6 +8,11 @@
 // more than that launch, 256 blocks do not. Measured (7B, one call): the launch with the norm inside 42.7 / 42.1 / 40.7 us at ring
 // depth 2 / 4 / 8 against 40.2 + 4.7 us for gemv_f16_kernel behind rmsnorm_kernel -- a 262 MB stream sustains 6.2-6.5 TB/s on this chip whatever is in
 // flight --, 969.3 -> 973.0 / 971.8 tokens/s at depth 4 / 8: depth 4 ships.
+// AM: the greedy sampler (argmax_kernel, gpu_kernels.h:448-493; llama2_q4.cu:384 -> sampler.h:47-49) as this launch's epilogue. Every wave keeps the
+// best of its own rows (the fp16-rounded logit it stores, first maximum = lowest row), a block leaves ONE candidate {value, row} (written through,
+// drained) and one returning arrival; the block that arrives last reads the 256 candidates, decides with argmax_kernel's rule (value, then the lower
+// index), copies the winner's embedding row for the next step where asked, writes the token ring and advances both position words. One launch and one
+// boundary fewer per greedy token; the logits are stored as before.
 #pragma once
 #include "gemv_strip.h"
 
@@ -21,9 +26,26 @@ struct StripClsLds {
     static constexpr unsigned BYTES = PART + NS * 256u;
 };
 
-template <int NS, bool NORM, int D>
+// the greedy sampler's tail inside the classifier launch: argmax_kernel's arguments + the launch's own hand-off words
+struct ClsArgmax {
+    unsigned* counter;                 // arrival counter, zero between launches (the last arriver re-arms it)
+    unsigned long long* cand;          // one {value bits, row} word per block
+    int* result;                       // SharedData::tokens
+    volatile int* pPos;                // SharedData::pos (pinned host word)
+    int* pPosGpu;                      // RunState::pos
+    int write_token;
+    q4_half* x_next;                   // the next step's residual stream (the winner's embedding row goes there) or null
+    const q4_half* table;
+    int dim;
+};
+__device__ __forceinline__ void argmax_merge(float& v, int& ix, float ov, int op) {      // argmax_kernel's rule: value, then the lower index
+    if (ov > v || (ov == v && op < ix)) { v = ov; ix = op; }
+}
+
+template <int NS, bool NORM, int D, bool AM = false>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w, const unsigned wbytes,
-                                                                    const unsigned rbase, const unsigned rrem, q4_half* __restrict__ out, const int n, const unsigned row_bytes) {
+                                                                    const unsigned rbase, const unsigned rrem, q4_half* __restrict__ out, const int n, const unsigned row_bytes,
+                                                                    const ClsArgmax am) {
     using L = StripClsLds<NS, D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -75,6 +97,10 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4
     for (int s = 0; s < NS; s++) X[s] = xn[s * 64 + lane];
     const unsigned char* wbase = smem + ring + lane * 16u;
 
+    float best = -INFINITY;          // (wave-uniform: wave_sum's result is)
+    int best_row = 0x7fffffff;
+    int token_pos = 0;
+    if (AM && tid == 0) token_pos = *am.pPosGpu;       // long landed when the epilogue wants it (the previous launch of the stream wrote it)
     for (int i = 0; i < nu; i++) {
         float sum = 0.f;
 #pragma unroll
@@ -91,7 +117,68 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4
         }
         float t = wave_sum(sum);
         t *= 1.0f;                                                             // alpha, gpu_kernels.h:135
-        if (lane == 0) out[r0 + (unsigned)wave + 16u * (unsigned)i] = f2h(t);
+        const q4_half th = f2h(t);
+        if (lane == 0) out[r0 + (unsigned)wave + 16u * (unsigned)i] = th;
+        if (AM) {                                                              // ascending rows, strict: the first maximum stays (argmax_kernel :160-173)
+            const float v = h2f(th);
+            if (v > best) { best = v; best_row = (int)(r0 + (unsigned)wave + 16u * (unsigned)i); }
+        }
+    }
+    if (!AM) return;
+    // ---- argmax_kernel as the epilogue of the launch
+    float* sval = reinterpret_cast<float*>(smem + L::PART);                    // (the rmsnorm partials are long read)
+    int* sidx = reinterpret_cast<int*>(smem + L::PART + 64);
+    int* sflag = reinterpret_cast<int*>(smem + L::PART + 128);
+    if (lane == 0) { sval[wave] = best; sidx[wave] = best_row; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = sval[0];
+        int ix = sidx[0];
+        for (int w = 1; w < STRIP_WAVES; w++) argmax_merge(v, ix, sval[w], sidx[w]);
+        const unsigned long long c = (unsigned long long)(unsigned)as_i(v) | ((unsigned long long)(unsigned)ix << 32);
+        unsigned long long* dst = am.cand + blockIdx.x;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(c) : "memory");   // written through, acknowledged
+        const unsigned old = __hip_atomic_fetch_add(am.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == gridDim.x - 1u;
+        if (last) __hip_atomic_store(am.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      // re-armed for the next launch
+        *sflag = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (*sflag == 0) return;
+    // the block that arrived last: every candidate is in memory
+    float v = -INFINITY;
+    int ix = 0x7fffffff;
+    for (unsigned b = tid; b < gridDim.x; b += STRIP_WAVES * 64) {
+        const unsigned long long c = __hip_atomic_load(am.cand + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        argmax_merge(v, ix, as_f((int)(unsigned)c), (int)(unsigned)(c >> 32));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int op = __shfl_xor(ix, off);
+        argmax_merge(v, ix, ov, op);
+    }
+    __syncthreads();                                                           // (thread 0 has read the block's own totals)
+    if (lane == 0) { sval[wave] = v; sidx[wave] = ix; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < STRIP_WAVES; w++) argmax_merge(v, ix, sval[w], sidx[w]);
+        if (ix == 0x7fffffff) ix = 0;                                          // all NaN / -inf
+        *sflag = ix;
+    }
+    if (am.x_next != nullptr) {                                                // (uniform: a kernel argument) every other block is done with x
+        __syncthreads();
+        const int token = *sflag;
+        // the upper waves copy the row while wave 0 publishes the token: two memory round trips side by side instead of in series
+        for (int u = (int)tid - 512; u >= 0 && u < (am.dim >> 3); u += 512)
+            reinterpret_cast<u32x4*>(am.x_next)[u] = reinterpret_cast<const u32x4*>(am.table + (size_t)token * am.dim)[u];
+    }
+    if (tid == 0) {
+        token_pos++;
+        if (am.write_token) am.result[token_pos] = ix;                         // gpu_kernels.h:486-487
+        __threadfence_system();                                                // the host may be spinning on *pPos (q4_wait_pos)
+        *am.pPos = token_pos;                                                  // :490 (unblocks the CPU)
+        *am.pPosGpu = token_pos;                                               // :491
     }
 }
 
@@ -111,28 +198,29 @@ int cls_strip_prepare() {
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
+        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
+        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
         opted = true;
     }
     return Q4_OK;
 }
-template <int NS, bool NORM, int D>
-static int launch_cls_strip_d(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d) {
+template <int NS, bool NORM, int D, bool AM>
+static int launch_cls_strip_d(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d, const ClsArgmax& am) {
     { const int rc = cls_strip_prepare(); if (rc) return rc; }
     const unsigned nb = (unsigned)cu_count();
     constexpr size_t smem = StripClsLds<NS, D>::BYTES;
-    Q4_LAUNCH((cls_strip_kernel<NS, NORM, D>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(rms_w),
-              (const void*)w, (unsigned)((size_t)d * n * 2), (unsigned)d / nb, (unsigned)d % nb, out, n, (unsigned)n * 2u);
+    Q4_LAUNCH((cls_strip_kernel<NS, NORM, D, AM>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(rms_w),
+              (const void*)w, (unsigned)((size_t)d * n * 2), (unsigned)d / nb, (unsigned)d % nb, out, n, (unsigned)n * 2u, am);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
-template <int NS, bool NORM>
-static int launch_cls_strip_ns(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d) {
-    return launch_cls_strip_d<NS, NORM, CLS_D>(out, x, rms_w, w, n, d);
-}
-// rms_w != nullptr: out = W . rmsnorm(x, rms_w) (x itself is left as it is); else out = W . x
-static int launch_cls_strip(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d) {
-    if (n == 4096) return rms_w ? launch_cls_strip_ns<8, true>(out, x, rms_w, w, n, d) : launch_cls_strip_ns<8, false>(out, x, nullptr, w, n, d);
-    return rms_w ? launch_cls_strip_ns<10, true>(out, x, rms_w, w, n, d) : launch_cls_strip_ns<10, false>(out, x, nullptr, w, n, d);
+// rms_w != nullptr: out = W . rmsnorm(x, rms_w) (x itself is left as it is); else out = W . x. am != nullptr (with rms_w): the greedy sampler as the
+// launch's epilogue
+static int launch_cls_strip(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d, const ClsArgmax* am) {
+    const ClsArgmax none = {};
+    if (am && rms_w) return n == 4096 ? launch_cls_strip_d<8, true, CLS_D, true>(out, x, rms_w, w, n, d, *am) : launch_cls_strip_d<10, true, CLS_D, true>(out, x, rms_w, w, n, d, *am);
+    if (n == 4096) return rms_w ? launch_cls_strip_d<8, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<8, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
+    return rms_w ? launch_cls_strip_d<10, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<10, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
 }
 
 }  // namespace q4

@@ -100,7 +100,15 @@ extern int g_ao_guard;
 extern int g_ao_vslice;
 extern int g_multi_steps;
 extern int g_engine;        // gemv_engine.hip
-int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab);   // q4_kernels.hip
+#ifdef Q4_PROFILING
+extern int g_cls_argmax;    // q4_kernels.hip: profiling knob 12, the greedy sampler as the classifier launch's epilogue
+#endif
+// the greedy sampler launch that would follow the classifier (argmax_kernel's arguments), for the classifier launch to take over; words: the
+// model's CLS hand-off words (one arrival counter, one pad, CLS_SYNC_BLOCKS candidates of 8 bytes), zero between launches
+enum { CLS_SYNC_BLOCKS = 1024, CLS_SYNC_WORDS = 2 + 2 * CLS_SYNC_BLOCKS };
+struct GreedyTail { unsigned* words; int* result; volatile int* pPos; int* pPosGpu; int write_token; q4_half* x_next; const q4_half* table; };
+static inline size_t cls_sync_offset(int dim) { return (attention_sync_words(dim) + 1) & ~(size_t)1; }   // 8-byte aligned, behind the attention words
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded);   // q4_kernels.hip
 int cls_strip_prepare();    // q4_kernels.hip (gemv_strip_cls.h): the same for the classifier's strips kernel
 int down_strip_prepare();   // gemv_plain.hip (gemv_strip_down.h): LDS opt-in of the 13B down projection's strips kernel, outside any stream capture
 extern unsigned long long* g_dbg;   // profiling build: device buffer for time stamps (q4_set_debug_buffer)

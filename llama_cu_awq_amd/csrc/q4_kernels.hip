@@ -288,6 +288,7 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 7) g_multi_steps = slots;
     if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
+    if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
     if (kind == 11) g_engine = slots;       // gate/up GEMV: 0 = gemv_q4_kernel, 1..3 = loader / consumer engine with that vmcnt lag
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
@@ -311,7 +312,7 @@ int q4_matmul_f16(q4_half* xout, const q4_half* x, const q4_half* w, int n, int 
     if ((n & 7) || (d & 7)) return Q4_ERR_UNSUPPORTED_SIZE;                         // llama2_q4.cu:215
     if (w_row_stride == -1) w_row_stride = n;                                       // :220
     if (w_row_stride & 7) return Q4_ERR_UNSUPPORTED_SIZE;
-    if (cls_strip_covers(n, d, batch, w_row_stride, alpha)) return launch_cls_strip(xout, x, nullptr, w, n, d);   // the classifier's shape: same bits, streamed through LDS-DMA rings
+    if (cls_strip_covers(n, d, batch, w_row_stride, alpha)) return launch_cls_strip(xout, x, nullptr, w, n, d, nullptr);   // the classifier's shape: same bits, streamed through LDS-DMA rings
     constexpr int ROWS = 2, WAVES = 4;
     dim3 grid(divUp(d, ROWS * WAVES), batch);
     if (n <= 2048)
@@ -500,8 +501,27 @@ int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pP
 // final rmsnorm + classifier (llama2_q4.cu:336, 339) as ONE launch where the strips form covers the shape: the norm is computed once per CU inside it and x
 // itself is left un-normalised (nothing reads it afterwards: the next step's embedding overwrites it); elsewhere the two launches of the reference
 namespace q4 {
-int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab) {
-    if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab);
+// tail != nullptr: the caller's next launch would be the greedy sampler with these arguments; *folded says whether this launch took it over
+// (only the strips form does: gemv_strip_cls.h)
+// Measured (7B and 13B -n 256, interleaved in one process, three calls): 967.6 / 967.1, 968.7 / 968.3, 550.8 / 551.0 tokens/s without / with -- the
+// epilogue's chain behind the last block (candidate written through and acknowledged, returning arrival, 2 KB of candidates, token ring over PCIe)
+// costs what the 6 us launch and its boundary cost. Bit-identical and NOT shipped: profiling knob 12.
+#ifdef Q4_PROFILING
+int g_cls_argmax = 0;
+#else
+enum { g_cls_argmax = 0 };
+#endif
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded) {
+    if (folded) *folded = false;
+    if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) {
+        if (tail && folded && g_cls_argmax && tail->words && (unsigned)cu_count() <= CLS_SYNC_BLOCKS) {
+            const ClsArgmax am = {tail->words, reinterpret_cast<unsigned long long*>(tail->words + 2), tail->result, tail->pPos, tail->pPosGpu, tail->write_token,
+                                  tail->x_next, tail->table, dim};
+            *folded = true;
+            return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab, &am);
+        }
+        return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab, nullptr);
+    }
     const int rc = q4_rmsnorm(x, x, rms_w, dim);
     return rc ? rc : q4_matmul_f16(logits, x, wcls, dim, vocab, 1, 0, 0, 0, -1, 1.0f);
 }

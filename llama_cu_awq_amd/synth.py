@@ -58,6 +58,11 @@ GEOMETRIES = {
     # thread, 40000 = the global-memory fallback (> 32 x 1024 entries)
     "v32k": (64, 96, 1, 2, 2, 32000, 32, 10000.0),
     "v40k": (64, 96, 1, 2, 2, 40000, 32, 10000.0),
+    # the classifier's strips launch (dim 4096 / 5120, >= 64 vocabulary rows per CU) with the greedy sampler as its epilogue, on a
+    # one-layer body: a vocabulary that splits evenly over 256 CUs and one that does not
+    "cls4096": (4096, 1408, 1, 32, 32, 32000, 300, 10000.0),
+    "cls5120": (5120, 1408, 1, 40, 40, 20000, 300, 10000.0),
+    "cls4096_ragged": (4096, 1408, 1, 32, 32, 16600, 300, 10000.0),
 }
 
 

@@ -330,3 +330,46 @@ def test_one_block_and_v_slice_forms_of_the_attention_role(q4, model, steps):
             af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
             err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())
             assert err <= (5e-3 if pos <= 128 else 1.2e-2), (pos, other, err)   # (histories differ by an ulp from early on; measured 5.4e-3 at 256)
+
+
+@pytest.mark.parametrize("name", ["cls4096", "cls5120", "cls4096_ragged"])
+@pytest.mark.parametrize("graphs", [1, 0])
+def test_greedy_sampler_inside_the_classifier_launch(q4, tmp_path, name, graphs):
+    """Knob 12 (measured neutral, not shipped: DESIGN.md section 9 item 19): where the classifier runs as strips (dim 4096 / 5120, a
+    production-size vocabulary) the greedy sampler (argmax_kernel, gpu_kernels.h:448-493) becomes that launch's epilogue: per-block
+    candidates, the last block to arrive decides. Every step's token must
+    be the argmax of the logits the same launch stored, ties to the lowest index, in the eight-steps-per-replay graphs (the winner's
+    embedding row fed to the next step), the single-step graphs and the eager sequence; positions advance by one per step."""
+    path = str(tmp_path / (name + ".bin"))
+    synth.write_model(path, name, seed=11)
+    L = q4.lib()
+    L.q4_set_use_graphs(graphs)
+    L.q4_set_gemv_early(12, 1)
+    try:
+        t = q4.Transformer(path)
+        prompt = [1, 400, 22, 7, 513]
+        steps = 60
+        gtoks, tps, timed, secs = t.generate_ids(prompt, steps)
+        t.reset(prompt)
+        ring = list(prompt)
+        for pos in range(steps):
+            t.run_transformer(pos >= len(prompt) - 1)
+            q4.synchronize()
+            assert int(t.pos()) == pos + 1
+            if pos + 1 >= len(prompt):
+                lg = t.logits().astype(np.float32)
+                assert int(t.token(pos + 1)) == int(np.argmax(lg)), pos
+                ring.append(int(t.token(pos + 1)))
+        n = min(len(gtoks), len(ring))
+        assert n >= steps - 1
+        stop = next((i for i in range(1, n) if ring[i] == 2), n)
+        assert list(gtoks[:stop]) == ring[:stop]
+        assert len(set(ring[len(prompt):])) > 3          # a degenerate ring would prove nothing
+        t.close()
+        L.q4_set_gemv_early(12, 0)                           # the same generation with argmax_kernel as a launch of its own
+        t = q4.Transformer(path)
+        assert list(t.generate_ids(prompt, steps)[0]) == list(gtoks)
+        t.close()
+    finally:
+        L.q4_set_gemv_early(12, 0)
+        L.q4_set_use_graphs(1)
