@@ -373,3 +373,44 @@ def test_greedy_sampler_inside_the_classifier_launch(q4, tmp_path, name, graphs)
     finally:
         L.q4_set_gemv_early(12, 0)
         L.q4_set_use_graphs(1)
+
+
+@pytest.mark.parametrize("model,steps", [("head128_k5120", 140), ("cls5120", 40)])
+@pytest.mark.parametrize("fusion", [3, 1])
+def test_qkv_strips_equal_the_wave_owned_kernel(q4, tmp_path, model, steps, fusion):
+    """The fused q/k/v launch of the 13B shape (K = N = 5120, head 128: rmsnorm + three GEMVs + RoPE + KV write) runs as strips
+    (csrc/gemv_strip_qkv.h: ten RoPE pairs per CU, dword-granular LDS-DMA gathers of scales and zeros, the (cos, sin) entries
+    requested between the ring's first pieces; measured slower than the wave-owned kernel and therefore not the product's choice). Knob
+    11 = -1 forces gemv_q4_kernel<MODE_QKV, 3, 4, true, 0, 1, true> everywhere, 0 is the product (the same kernel for this launch), 8 strips
+    wherever covered. Same arithmetic in the same order: logits AND every K / V row written must agree bit for bit, with
+    the epoch word advanced for the attention -> o-proj launch behind it (fusion level 3) and without (level 1)."""
+    L = q4.lib()
+    path = _model_file(model) if model == "head128_k5120" else str(tmp_path / (model + ".bin"))
+    if model != "head128_k5120":
+        synth.write_model(path, model, seed=11)
+    outs = {}
+    try:
+        for engine in (-1, 0, 8):
+            L.q4_set_gemv_early(11, engine)
+            L.q4_set_fusion(fusion)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in (0, 1, 2, 17, 64, 127, 128, steps - 1):
+                    q4.synchronize()
+                    k, v = t.kv_row(0, pos)
+                    got.append((pos, t.logits().view(np.uint16).copy(), k.view(np.uint16).copy(), v.view(np.uint16).copy()))
+            q4.check(L.q4_handoff_status(t.state))
+            outs[engine] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            t.close()
+    finally:
+        L.q4_set_gemv_early(11, 0)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)
+    assert np.isfinite(outs[-1][0][-1][1].view(np.float16).astype(np.float32)).all()
+    for engine in (0, 8):
+        assert outs[engine][1] == outs[-1][1], engine
+        for (pos, lg, k, v), (_, lg0, k0, v0) in zip(outs[engine][0], outs[-1][0]):
+            assert np.array_equal(k, k0) and np.array_equal(v, v0), (engine, pos, "KV rows")
+            assert np.array_equal(lg, lg0), (engine, pos, "logits")
