@@ -265,6 +265,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     } else {
                         c = __builtin_fmaf(h2f(sc), t, c);
                     }
+                    // K = 5120: the piece's arithmetic stays HERE, in front of the next piece's wait. Left alone hipcc sinks a unit's 48 dot products behind
+                    // the NEXT unit's three waits (and the last two units' behind the group's last wait): the wave sits in vmcnt with landed pieces
+                    // unmultiplied. 13B -n 256: 565.6 -> 581.2 tokens/s (tools/ab.py, one call). At K = 4096 hipcc keeps a unit's 32 dot products behind
+                    // the unit's own two waits, and pinning them per piece is neutral (Mistral geometry 911.8 vs 910.8): left to the compiler
+                    if (TS == 3) asm volatile("" : "+v"(c));
                 }
                 cs[r] = c;
                 if (STAMPS) { asm volatile("" : "+v"(c)); if (wave == 0 && i < 8) SSTAMP(4 + i); if (i == nu - 1) SSTAMP(48 + wave); }
