@@ -22,7 +22,7 @@ t = api.Transformer(path)
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
 t.generate_ids(prompt, 64)
 for rep in range(3):
-    for knob in (0, 8):
+    for knob in [int(v) for v in os.environ.get("KNOBS", "0,8").split(",")]:
         L.q4_set_gemv_early(11, knob)
         t.reset(prompt)
         for pos in range(40):
