@@ -22,7 +22,7 @@ t = api.Transformer(path)
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
 t.generate_ids(prompt, 64)
 for rep in range(3):
-    for knob in [int(v) for v in os.environ.get("KNOBS", "0,8").split(",")]:
+    for knob in [int(v) for v in os.environ.get("KNOBS", "0,8").split(",")]:   # 17 / 18: gate/up strips with / without the last round dealt by pieces, every other launch the product's
         L.q4_set_gemv_early(11, knob)
         t.reset(prompt)
         for pos in range(40):
