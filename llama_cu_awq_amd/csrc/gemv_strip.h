@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     const int e = (TS * r + ks) & DM1;                      // j % D (4 TS g4 is a multiple of D)
                     const bool hs = TS == 3 && ks == 2;                     // the half slot
                     if (!PACED) {
-                        if (j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();   // piece j has landed
+                        // piece j has landed. D = 2: exact -- the stream's last piece but one does not wait for the last (13B 580.3 -> 583.2, Mistral geometry
+                        // 913.2 -> 914.4 tokens/s, tools/ab.py); deeper rings (profiling) drain at their last D pieces
+                        if (D == 2 ? j + 1 < npieces : j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();
                     } else {
                         if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();     // pieces < I - 1 have landed, and I >= j + 2: piece j has
                         if (I < npieces && I - j < D) { issue(I); I++; }    // at most one was in flight: now two; the entry's last reader was piece I - D < j

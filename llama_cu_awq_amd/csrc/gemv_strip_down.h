@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
             for (int ks = 0; ks < SH; ks++) {
                 const int j = PPU * i + ks;
                 const bool last = ks == SH - 1, hs = SHARED && last;
-                if (j + 2 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();        // piece j has landed
+                if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();        // piece j has landed (the last piece but one does not wait for the last)
                 const unsigned unit = ubase + 64u * (unsigned)ks + (hs ? lu : lane);   // the uint4 unit this lane multiplies
                 const bool live = !last || (SHARED ? (upper == odd && lu < tail && unit < uend) : (lane < tail && unit < uend));
                 const unsigned uj = unit < uend ? unit : uend - 1u;
