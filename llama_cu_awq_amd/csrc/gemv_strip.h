@@ -298,6 +298,167 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
 }
 #undef SSTAMP
 
+// K = 5120 with PAIR units: a wave's unit is a pair of adjacent columns (c even, c + 1) of one matrix = FIVE full 1 KiB pieces -- c k-slot 0, c k-slot 1,
+// c + 1 k-slot 0, c + 1 k-slot 1 and ONE piece for both columns' last 32 uint4 (lanes 0-31 fetch column c's, lanes 32-63 column c + 1's: the load and the
+// single dequant-dot evaluation of gemv_q4.h's shared half slot) -- instead of two units of two pieces and a 512-byte one. A wave's stream is a latency
+// chain of one memory round trip per two pieces whatever their size, so the 512-byte pieces cost bandwidth (a third of ffn_strip_kernel<..., 3>'s DMA
+// instructions carried half a KiB: 6.5 TB/s in the steady state) and every sixth piece is saved. Same per-lane chains (k-slot 0, k-slot 1, half slot as a
+// product and a sum on the column's own half of the wave), same reduction: bit for bit (tests/prof_cases.py). Needs an even number of columns per CU.
+template <bool NORM>
+__global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
+                                                                          const unsigned cbase, const GemvArgs a) {
+    constexpr int TS = 3, D = 2, PPU = 5;              // k-slots of a column, ring depth, pieces per pair unit
+    constexpr unsigned CB = 2560u, G = 40u, ZW = 5u;
+    constexpr int NSTAGE = 10;
+    using L = StripLds<D, TS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned c0 = blockIdx.x * cbase;            // (even)
+    const int nc = (int)cbase;
+    const int mat = wave & 1;
+    const int npu = (nc - wave + 15) >> 4;             // this wave's pair units: pu = wave + 16 i of the block's nc (nc / 2 pairs x 2 matrices): pair wave / 2 + 8 i, matrix wave % 2
+    const int npieces = PPU * npu;
+    const unsigned voff = lane * 16u;
+    const bool upper = lane >= 32u;
+    const unsigned voff_pair = (upper ? CB : 0u) + (lane & 31u) * 16u;   // the shared piece: column c's tail below, column c + 1's above
+    const bool stager = wave < NSTAGE;
+
+    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
+    if (stager) {
+        const u32x4* px = arg_x + tid;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
+        if (NORM) {
+            const u32x4* pw = arg_rms + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
+        }
+    }
+    constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);
+    if (wave < 2 * NSIDE) {
+        const int m = wave >= NSIDE, p = wave - NSIDE * m;
+        if (p < (int)L::NS_S) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * (G * 2u) + p * 1024u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff, rz, c0 * (ZW * 4u) + (p - (int)L::NS_S) * 1024u);
+        }
+    }
+    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
+    const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
+    const unsigned cl0 = 2u * ((unsigned)wave >> 1);                      // first column of this wave's pair 0, local to the block; pair i: + 16 i
+    const unsigned soff0 = (c0 + cl0) * CB;
+    auto issue = [&](int i, int k) {                    // piece k of pair unit i (k a constant at every call site)
+        const unsigned dst = ring + (unsigned)((PPU * i + k) & (D - 1)) * 1024u, so = soff0 + (unsigned)i * (16u * CB);
+        if (k == 4) dma_piece(dst, voff_pair, rw, so + 2048u);
+        else dma_piece(dst, voff, rw, so + (unsigned)(k >> 1) * CB + (unsigned)(k & 1) * 1024u);
+    };
+    if (npieces > 0) { issue(0, 0); issue(0, 1); }
+
+    u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
+    float* sx = reinterpret_cast<float*>(smem + L::SX);
+    float* part = reinterpret_cast<float*>(smem + L::PART);
+    float* tot = reinterpret_cast<float*>(smem + L::TOT);
+    if (npieces > 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(xraw), "+v"(wraw) : : "memory");   // all but the weight pieces
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xraw), "+v"(wraw) : : "memory");
+    if (NORM) {
+        if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;
+        block_barrier_lds();
+    }
+    if (stager) {
+        float ss = 1.f;
+        if (NORM) ss = rms_scale_from_partials<TS * 256>(part, TS * 256, a.K);
+        u32x4 v = xraw;
+        if (NORM) v = rms_apply8(v, wraw, ss);
+        const u32x4 pv = permute_x8(v);
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        float cb = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+        cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+        const unsigned j = tid >> 2, d = tid & 3u;
+        xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+        if (d == 0) sx[j] = cb * -9.5367431640625e-07f;
+    }
+    block_barrier_lds();                               // x staged; side data landed
+    u32x4 X[TS][4];
+    float corr[TS];
+#pragma unroll
+    for (int ks = 0; ks < TS; ks++) {
+        const unsigned lu = ks == 2 ? (lane & 31u) : lane;
+#pragma unroll
+        for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lu];
+        corr[ks] = sx[ks * 64 + lu];
+    }
+    const unsigned char* wbase = smem + ring + lane * 16u;
+    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + (cl0 * G + (lane >> 2)) * 2u;    // + i * 16 columns * 80 B, + 80 for the pair's second column
+    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + (cl0 * ZW + (lane >> 5)) * 4u;   // + i * 16 columns * 20 B, + 20
+    const unsigned zsh = ((lane >> 2) & 7u) * 4u;
+
+    for (int g2 = 0; g2 * 2 < npu; g2++) {
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};             // pair 2 g2: columns c, c + 1; pair 2 g2 + 1: columns c, c + 1
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = g2 * 2 + r;
+            if (i < npu) {
+                float cA = 0.f, cB = 0.f;
+#pragma unroll
+                for (int k = 0; k < PPU; k++) {
+                    const int j = PPU * i + k;
+                    const int e = (PPU * r + k) & (D - 1);                  // j % D (two pair units are ten pieces)
+                    if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();   // piece j has landed
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
+                    const int ks = k == 4 ? 2 : (k & 1);
+                    const unsigned colsel = k == 4 ? (upper ? 1u : 0u) : (unsigned)(k >> 1);   // which column of the pair this lane works for
+                    // scale and zero word of this lane's group: 16 ks + lane / 4, in the shared piece 32 + (lane % 32) / 4 of the lane's own column
+                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + ((unsigned)i * 16u + colsel) * (G * 2u) + (k == 4 ? 64 - (int)(upper ? 16u : 0u) : ks * 32));
+                    const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + ((unsigned)i * 16u + colsel) * (ZW * 4u) + (k == 4 ? 16 - (int)(upper ? 4u : 0u) : ks * 8));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
+                    if (j + D < npieces) issue(i + (k + D) / PPU, (k + D) % PPU);
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d];
+                        const unsigned tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[ks][d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[ks][d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[ks][d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[ks][d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((zw >> zsh) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr[ks], t);
+                    if (k == 4) {        // gemv_q4.h's shared half slot: a product and a sum, each half of the wave for its own column
+                        const float v = h2f(sc) * t;
+                        cA += upper ? 0.f : v;
+                        cB += upper ? v : 0.f;
+                    } else if (k < 2) {
+                        cA = __builtin_fmaf(h2f(sc), t, cA);
+                    } else {
+                        cB = __builtin_fmaf(h2f(sc), t, cB);
+                    }
+                    asm volatile("" : "+v"(cA), "+v"(cB));                  // the piece's arithmetic stays in front of the next piece's wait (section 3.1b)
+                }
+                cs[2 * r] = cA;
+                cs[2 * r + 1] = cB;
+            }
+        }
+        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row: pair (2 g2 + row / 2), column row % 2
+        const int row = lane >> 4;
+        if ((lane & 15u) == 0 && g2 * 2 + (row >> 1) < npu)
+            tot[2 * (cl0 + 16u * (unsigned)(g2 * 2 + (row >> 1)) + (unsigned)(row & 1)) + mat] = total;   // [column][matrix]
+    }
+    block_barrier_lds();
+    if ((int)tid < nc) {
+        const float g = tot[2 * tid], u = tot[2 * tid + 1];
+        float val = g;
+        val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
+        val *= u;                                       // :272
+        a.out[0][c0 + tid] = f2h(val);
+    }
+}
+
 // Shapes: K = 4096 (two 1 KiB pieces per column), 16 .. 56 columns per CU, on a stream that may use every CU (the blocks do not wait for
 // each other: on a CU-masked stream the form would be correct, only slow). g_engine: 0 = the product's choice -- strips from
 // STRIP_MIN_COLS columns per CU on, where the wave-owned kernel's grid needs a seventh row of blocks per CU and strips measure
@@ -315,7 +476,7 @@ static bool ffn_strip_shape(const GemvArgs& a) {
     return k && a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
 }
 static bool ffn_strip_covers(const GemvArgs& a) {
-    if (g_engine == 0 || g_engine == 15) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);   // (15: profiling, the product's gate/up choice without the down-projection strips)
+    if (g_engine == 0 || g_engine == 15 || g_engine == 19) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);   // (15: profiling, the product's gate/up choice without the down-projection strips)
 #ifdef Q4_PROFILING
     return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && ffn_strip_shape(a);
 #else
@@ -338,6 +499,21 @@ static int launch_strip(const GemvArgs& a) {
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
+// K = 5120 as pair units: every CU the same even number of columns
+static bool strip_pairs(const GemvArgs& a) { return strip_k5120(a) && a.N % (2 * cu_count()) == 0; }
+static int launch_strip_pair(const GemvArgs& a) {
+    constexpr size_t smem = StripLds<2, 3>::BYTES;
+    static_assert(smem <= 64 * 1024, "no opt-in");
+    const unsigned nb = (unsigned)cu_count();
+    if (a.rms_w)
+        Q4_LAUNCH((ffn_strip_pair_kernel<true>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
+                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / nb, a);
+    else
+        Q4_LAUNCH((ffn_strip_pair_kernel<false>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
+                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / nb, a);
+    Q4_LAUNCH_CHECK();
+    return Q4_OK;
+}
 #ifdef Q4_PROFILING
 template <bool NORM, bool STAMPS>
 static int launch_strip_setting(const GemvArgs& a) {
@@ -352,6 +528,7 @@ static int launch_strip_setting(const GemvArgs& a) {
 }
 static int launch_ffn_strip(const GemvArgs& a) {
     const bool norm = a.rms_w != nullptr;
+    if (g_engine != 19 && g_engine != 9 && strip_pairs(a)) return launch_strip_pair(a);   // (19: the column-unit form of K = 5120, for the A/B)
     if (strip_k5120(a)) {
         if (g_engine == 9) return norm ? launch_strip<true, 4, 0, false, 3>(a) : launch_strip<false, 4, 0, false, 3>(a);
         return norm ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
@@ -361,6 +538,7 @@ static int launch_ffn_strip(const GemvArgs& a) {
 }
 #else
 static int launch_ffn_strip(const GemvArgs& a) {
+    if (strip_pairs(a)) return launch_strip_pair(a);
     if (strip_k5120(a)) return a.rms_w ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
     return a.rms_w ? launch_strip<true, 2, 0, false>(a) : launch_strip<false, 2, 0, false>(a);
 }

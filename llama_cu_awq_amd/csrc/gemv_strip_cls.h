@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4
 
 // n = 4096 or 5120 inputs (8 or 10 pieces per row), contiguous rows, one right-hand side, alpha = 1, at least 64 rows per CU, a stream that may use every CU
 static bool cls_strip_covers(int n, int d, int batch, int w_row_stride, float alpha) {
-    if (g_engine != 0 && g_engine != 8) return false;
+    if (g_engine != 0 && g_engine != 8 && g_engine != 19) return false;
     const int nb = cu_count();
     return (n == 4096 || n == 5120) && batch == 1 && w_row_stride == n && alpha == 1.0f && d / nb >= 64 && (long long)d * n * 2 < (1ll << 31) &&
            g_ablate == 0 && stream_cu_count() == nb;

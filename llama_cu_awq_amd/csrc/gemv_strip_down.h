@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
 // (which forces strips wherever the shape is covered).
 static bool down_strip_covers(const GemvArgs& a, bool shared) {
     const int nb = cu_count();
-    if (g_engine == 0) {
+    if (g_engine == 0 || g_engine == 19) {
         // the product's choice: where the K-split kernel's grid (8 columns per block) leaves the CUs uneven -- 13B: 640 blocks = 2.5 per CU, the launch
         // pays for three; strips 536 -> 546 tokens/s. Where it divides evenly the K-split kernel is faster (Mistral geometry, K = 14336, 512 blocks:
         // strips 899 -> 890 tokens/s; Llama-2-7B 962 -> 936)

@@ -40,7 +40,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
         assert np.array_equal(o, outs[(-1, 0)]), key
 
 
-@pytest.mark.parametrize("N", [13824, 13824 + 8, 12800, 5120])
+@pytest.mark.parametrize("N", [13824, 13824 + 8, 12800, 5120, 14336, 8192])
 def test_gate_up_strips_at_k5120_equal_the_shared_half_slot_kernel(q4, rng, N):
     """K = 5120 (13B): a column is two 1 KiB pieces and a half one. The strips form (csrc/gemv_strip.h, TS = 3) gives the half piece to the
     lower half of the wave for even columns and to the upper half for odd ones and adds its term as a product and a sum -- the lanes and
@@ -53,7 +53,7 @@ def test_gate_up_strips_at_k5120_equal_the_shared_half_slot_kernel(q4, rng, N):
     dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (-1, 0, 8, 9):
+        for engine in (-1, 0, 8, 9, 19):     # 19: column units (two pieces and a half one) where 0 / 8 run pair units (five full pieces per column pair)
             L.q4_set_gemv_early(11, engine)
             for rep in range(4):
                 dout = q4.DevBuf(nbytes=N * 2)
