@@ -38,7 +38,9 @@ namespace q4 {
 
 int g_engine = 0;   // 0: the product's choice (gemv_strip.h: strips for wide matrices, gemv_q4_kernel<MODE_FFN> otherwise). Profiling build: -1 = gemv_q4_kernel
                     // always; 1..3: the loader / consumer engine with LAG = value where the shape is covered (1 measured best); 5, 6 = LAG 1, 2 with the
-                    // consumers' next-slot prefetch; 8..14: a strips variant
+                    // consumers' next-slot prefetch; 8..14: a strips variant (8 also: every other strips form wherever its shape is covered -- down projection,
+                    // classifier, the 13B q/k/v launch of gemv_strip_qkv.h); 15: the product's gate/up choice without the down-projection strips; 19: the
+                    // product with K = 5120 gate/up on column units instead of pair units
 
 #ifdef Q4_PROFILING
 

@@ -289,7 +289,7 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
     if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
-    if (kind == 11) g_engine = slots;       // gate/up GEMV: 0 = gemv_q4_kernel, 1..3 = loader / consumer engine with that vmcnt lag
+    if (kind == 11) g_engine = slots;       // the GEMV forms: 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings (gemv_engine.hip)
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
 }
