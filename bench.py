@@ -365,6 +365,24 @@ def main():
             gb = GB_PER_TOKEN[(mname, n)]
             extra["llama2_%s_n%d" % (mname, n)] = {"tokens_per_s": round(best, 1), "ms_per_token": round(1000.0 / best, 4), "GB_per_token": gb,
                                                     "frac_of_8TBps": round(best * gb / HBM_PEAK_GBS, 4)}
+            if mname == "13b":
+                # the 13B launches by HIP events inside the eager network, like roofline.per_kernel above (gate/up and the down projection run as
+                # strips there: csrc/gemv_strip.h, gemv_strip_down.h)
+                class _C2:
+                    pass
+                c2 = _C2()
+                c2.dim, c2.hidden_dim, c2.vocab_size = g2[0], g2[1], g2[5]
+                kb2 = kernel_bytes(c2)
+                t2.reset(PROMPT_IDS)
+                for pos in range(64):
+                    t2.run_transformer(pos >= len(PROMPT_IDS) - 1)
+                    api.synchronize()
+                pk = {}
+                for cls, nm, kid in ((8, kb2[0][0], 0), (1, "qkv_rmsnorm_rope_q4", 3), (16, "gemv_q4_hidden_to_dim_accum", 2)):
+                    a_, mn_, mx_, n_ = t2.bench_in_network(cls, 8)
+                    pk[nm] = {"hip_event_us": round(a_, 3), "bytes": kb2[kid][1], "GBps": round(kb2[kid][1] / a_ / 1e3, 1),
+                              "frac": round(kb2[kid][1] / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_}
+                extra["llama2_%s_n%d" % (mname, n)]["per_kernel"] = pk
             t2.close()
         tr = api.Transformer(path, temperature=0.0)
 
