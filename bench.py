@@ -193,7 +193,7 @@ def main():
             if os.path.exists(cpath):
                 import csv
                 for r in csv.DictReader(open(cpath)):
-                    if "gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"]:   # the fused gate/up launch (wide matrices: the strips form, csrc/gemv_strip.h)
+                    if "gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]:   # the fused gate/up launch (wide matrices: the strips form, csrc/gemv_strip.h)
                         rocprof_us, rocprof_src = float(r["avg_us"]), "profiles/" + os.path.basename(cpath)
                         break
             if rocprof_us is not None:
@@ -232,7 +232,7 @@ def main():
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
                             "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
-                            kb[0][0]: ("gemv_q4_kernel<2,", "ffn_strip_kernel<")}
+                            kb[0][0]: ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
                 for nm_, pre_ in prefixes.items():
                     ratios = [e_["traffic_over_algorithmic"] for k_, e_ in tj_all.get("%s_n%d" % (args.model, ntok), {}).items()
                               if isinstance(e_, dict) and k_.replace("q4::", "").startswith(pre_) and "traffic_over_algorithmic" in e_]   # (str.startswith takes a tuple too)

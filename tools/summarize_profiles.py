@@ -61,7 +61,7 @@ def algorithmic(kernel, model, ntok):
     """algorithmic bytes per launch of a kernel of the decode network (weights + metadata + vectors in / out)"""
     d, h, v, _ = GEOM[model]
     kernel = kernel[4:] if kernel.startswith("q4::") else kernel
-    if kernel.startswith("gemv_q4_kernel<2") or kernel.startswith("ffn_engine_kernel") or kernel.startswith("ffn_strip_kernel"):
+    if kernel.startswith("gemv_q4_kernel<2") or kernel.startswith("ffn_engine_kernel") or kernel.startswith("ffn_strip_kernel") or kernel.startswith("ffn_strip_pair_kernel"):
         return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
     if kernel.startswith("gemv_q4_kernel<1"):
         return 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2
