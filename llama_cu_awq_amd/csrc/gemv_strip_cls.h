@@ -198,8 +198,10 @@ int cls_strip_prepare() {
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
+#ifdef Q4_PROFILING     // the sampler-epilogue form exists in the profiling build only (knob 12)
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
         Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
+#endif
         opted = true;
     }
     return Q4_OK;
@@ -218,7 +220,11 @@ static int launch_cls_strip_d(q4_half* out, const q4_half* x, const q4_half* rms
 // launch's epilogue
 static int launch_cls_strip(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d, const ClsArgmax* am) {
     const ClsArgmax none = {};
+#ifdef Q4_PROFILING
     if (am && rms_w) return n == 4096 ? launch_cls_strip_d<8, true, CLS_D, true>(out, x, rms_w, w, n, d, *am) : launch_cls_strip_d<10, true, CLS_D, true>(out, x, rms_w, w, n, d, *am);
+#else
+    (void)am;
+#endif
     if (n == 4096) return rms_w ? launch_cls_strip_d<8, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<8, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
     return rms_w ? launch_cls_strip_d<10, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<10, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
 }
