@@ -52,9 +52,20 @@ struct AttShape {
     static constexpr int LB = ATT == 1 || ATT == 6 ? 128 : 0;   // forms entered above position 127 only (bins > 128)
 };
 
+// The eight pointers every block needs FIRST lead the argument list: built with kernel-argument preload (csrc/Makefile, ATTNFLAGS) they arrive in SGPRs with the
+// wave -- hand-off words (epoch), position word, q, K and V rows for the attention role; the o-proj role's weight, zero and scale tensors -- instead of behind
+// a scalar round trip to the argument segment; the struct carries everything else (and the same eight values, unused).
 template <int SLOTS, bool HALF, int ATT, int LPR>
-__global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(const AttOprojArgs a) {
+__global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned* const lead_sync, const int* const lead_pos, const q4_half* const lead_q, const q4_half* const lead_k,
+                                                                        const q4_half* const lead_v, const uint32_t* const lead_w, const uint32_t* const lead_z, const q4_half* const lead_s,
+                                                                        const AttOprojArgs a0) {
     constexpr int NW = LA_WAVES;
+    AttOprojArgs a = a0;
+    if constexpr (ATT >= 2 && ATT <= 4) {     // the split-context forms only: below bin 512 the role's entry code is hand-placed and lost 1.3 % with these copies
+        a.sync = lead_sync;
+        a.split.pPos = lead_pos; a.split.q = lead_q; a.split.key_cache = lead_k; a.split.value_cache = lead_v;
+        a.oproj.m[0].w = lead_w; a.oproj.m[0].z = lead_z; a.oproj.m[0].s = lead_s;
+    }
     constexpr int U = AttShape<LPR, ATT>::U;
     static_assert(U >= 1, "rows in flight");
     const unsigned b = blockIdx.x;
@@ -110,7 +121,7 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
                 *max_blocks_per_cu = n;                                                                                   \
                 return Q4_OK;                                                                                             \
             }                                                                                                             \
-            Q4_LAUNCH(kernel, grid, block, smem, a);                                                                      \
+            Q4_LAUNCH(kernel, grid, block, smem, a.sync, a.att.pPos, a.att.q, a.att.key_cache, a.att.value_cache, a.oproj.m[0].w, a.oproj.m[0].z, a.oproj.m[0].s, a); \
             Q4_LAUNCH_CHECK();                                                                                            \
             return Q4_OK;                                                                                                 \
         };                                                                                                                \
