@@ -464,9 +464,16 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const 
 // STRIP_MIN_COLS columns per CU on, where the wave-owned kernel's grid needs a seventh row of blocks per CU and strips measure
 // faster (tools/sweep_strips.py, per launch in a graph: 12800 columns 11.83 -> 10.56 us, 13312 11.89 -> 10.96, the Mistral / Llama-3
 // hidden size 14336 12.4 -> 11.45, 885 -> 902 tokens/s on the Mistral-7B geometry; up to 48 columns per CU -- Llama-2-7B's 11008 is 43 --
-// the two are level and the wave-owned kernel stays) --; the profiling build also takes -1 = never, 8 .. 14 = this variant wherever
-// the shape is covered.
-constexpr int STRIP_MIN_COLS = 49;
+// the two were level at first: the threshold was 49 until the strips' kernel arguments were preloaded (csrc/Makefile GEMVFLAGS) and their last
+// piece but one stopped draining. With both, per launch in a graph, wave-owned | strips: 16 columns per CU 4.92 | 5.39 us, 20: 5.88 | 5.92, 24: 6.25 |
+// 6.46, 28: 7.12 | 6.98, 32: 7.78 | 7.75, 36: 8.57 | 8.23, 40: 9.15 | 9.01, 43 (Llama-2-7B): 10.12 | 9.69, 46: 10.08 | 9.72; Llama-2-7B -n 256
+// 982.7 -> 990.8, -n 2048 872.6 -> 879.5 tokens/s (tools/ab.py against a build with the threshold at 43)) --; the profiling build also takes
+// -1 = never, 8 .. 14 = this variant wherever the shape is covered.
+#ifdef Q4_STRIP_MIN_COLS
+constexpr int STRIP_MIN_COLS = Q4_STRIP_MIN_COLS;   // (make exp EXPFLAGS_GEMV=-DQ4_STRIP_MIN_COLS=49: the wave-owned kernel for Llama-2-7B's gate/up, for the A/B)
+#else
+constexpr int STRIP_MIN_COLS = 36;
+#endif
 extern int g_engine;
 static inline bool strip_k5120(const GemvArgs& a) { return a.K == 5120 && a.pw4 == 160 && a.sh == 40 && a.pzh == 5; }
 static bool ffn_strip_shape(const GemvArgs& a) {

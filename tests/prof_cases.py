@@ -16,7 +16,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     """The fused gate/up GEMV at K = 4096 has three forms (knob 11): -1 = gemv_q4_kernel<MODE_FFN> (the wave-owned kernel), 8 .. 14 = "strips"
     (csrc/gemv_strip.h: sixteen self-loading waves per CU on LDS-DMA rings; ring depth 2 / 4 / 8, plain and paced issue), 1 .. 6 = the
     loader / consumer engine (csrc/gemv_engine.hip: one loader wave, eight consumer waves, an 8 x 16 KiB ring; vmcnt lag, + 4 with the
-    consumers' next-slot prefetch); 0 = the product's choice (strips from 49 columns per CU on, i.e. for 14336 here). Same arithmetic in
+    consumers' next-slot prefetch); 0 = the product's choice (strips from 36 columns per CU on, i.e. for 11008 and 14336 here). Same arithmetic in
     the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split over the CUs and the smallest covered width,
     repeated launches (a race between a fill and a read would show as a run-to-run difference)."""
     L = q4.lib()
@@ -45,7 +45,7 @@ def test_gate_up_strips_at_k5120_equal_the_shared_half_slot_kernel(q4, rng, N):
     """K = 5120 (13B): a column is two 1 KiB pieces and a half one. The strips form (csrc/gemv_strip.h, TS = 3) gives the half piece to the
     lower half of the wave for even columns and to the upper half for odd ones and adds its term as a product and a sum -- the lanes and
     the operations of gemv_q4.h's shared half slot -- so the two forms must agree bit for bit: knob 11 = -1 (wave-owned kernel), 0 (the
-    product's choice: strips from 49 columns per CU on), 8 / 9 (strips, ring depth 2 / 4, wherever the shape is covered)."""
+    product's choice: strips from 36 columns per CU on), 8 / 9 (strips, ring depth 2 / 4, wherever the shape is covered)."""
     L = q4.lib()
     K = 5120
     x = rng.standard_normal(K).astype(np.float16)

@@ -60,9 +60,9 @@ def test_matmul_q4_kv_addressing(q4, orc, rng):
     assert (got[: loff + pos * N] == 0).all() and (got[loff + (pos + 1) * N:] == 0).all()
 
 
-# (4096, 14336) and (4096, 12552) run as "strips" (csrc/gemv_strip.h: from 49 columns per CU on; 12552 = a ragged split, 49 or 50
-# columns per CU), (4096, 12536) just below that stays with the wave-owned kernel
-@pytest.mark.parametrize("K,N", [(4096, 11008), (5120, 13824), (256, 352), (8192, 28672), (4096, 14336), (4096, 12552), (4096, 12536)])
+# (4096, 11008), (4096, 14336), (4096, 12552) and (4096, 12536) run as "strips" (csrc/gemv_strip.h: from 36 columns per CU on; 12552 and 12536 = ragged splits, 49 or
+# 50 / 48 or 49 columns per CU), (4096, 9208) = 35 or 36 per CU just below that and (4096, 8192) stay with the wave-owned kernel
+@pytest.mark.parametrize("K,N", [(4096, 11008), (5120, 13824), (256, 352), (8192, 28672), (4096, 14336), (4096, 12552), (4096, 12536), (4096, 9208), (4096, 9216), (4096, 8192)])
 def test_ffn_matvec_silu(q4, orc, rng, K, N):
     g = synth.random_qweight(rng, K, N)
     u = synth.random_qweight(rng, K, N)

@@ -17,7 +17,7 @@ api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
 dim = 4096
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
-for cols in (40, 43, 44, 46, 48, 50, 52, 56):
+for cols in [int(c) for c in os.environ.get("COLS", "40,43,44,46,48,50,52,56").split(",")]:
     hidden = cols * 256
     path = "/tmp/llama2_q4_synth_d%d_h%d.bin" % (dim, hidden)
     geom = (dim, hidden, 8, dim // 128, dim // 128, 512, 256, 10000.0)
