@@ -115,7 +115,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
     print(model, ntok, json.dumps(per)[:600])
 if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
     for k, e in traffic["7b_n256"].items():
-        if k.replace("q4::", "").startswith("gemv_q4_kernel<2") or k.replace("q4::", "").startswith("ffn_engine_kernel"):
+        if k.replace("q4::", "").startswith(("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")):   # the fused gate/up launch in whatever form the product runs it
             traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
 traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
@@ -131,7 +131,7 @@ sq = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(src, "pmc_k0_sq", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemv_q4_kernel<2" in r["Kernel_Name"] or "ffn_engine_kernel" in r["Kernel_Name"]:
+        if any(n in r["Kernel_Name"] for n in ("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")):
             sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {"kernel": short(r["Kernel_Name"]), "vgpr": int(r["VGPR_Count"]), "workgroup": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
 if sq:
