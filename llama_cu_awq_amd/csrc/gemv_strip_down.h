@@ -194,11 +194,12 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
 static bool down_strip_covers(const GemvArgs& a, bool shared) {
     const int nb = cu_count();
     if (g_engine == 0 || g_engine == 19) {
-        // the product's choice: where the K-split kernel's grid (8 columns per block) leaves the CUs uneven -- 13B: 640 blocks = 2.5 per CU, the launch
-        // pays for three; strips 536 -> 546 tokens/s. Where it divides evenly the K-split kernel is faster (Mistral geometry, K = 14336, 512 blocks:
-        // strips 899 -> 890 tokens/s; Llama-2-7B 962 -> 936)
-        const int blocks = divUp(a.N, 8), rem = blocks % nb;
-        if (!shared || rem == 0 || rem * 10 > nb * 6) return false;
+        // the product's choice: the shared-slot form (four slots per k-part, K = 13824 / 14336). It was taken only where the K-split kernel's grid (8 columns
+        // per block) leaves the CUs uneven -- 13B: 640 blocks = 2.5 per CU, the launch pays for three; strips 536 -> 546 tokens/s -- because on an even grid
+        // the K-split kernel was faster (Mistral geometry, K = 14336, 512 blocks: strips 899 -> 890 tokens/s). With the strips' kernel arguments preloaded
+        // (csrc/Makefile GEMVFLAGS), their arithmetic pinned per piece and the exact tail wait they win there too: 7.63 -> 7.47 us per launch, 908.3 -> 914.1
+        // tokens/s. The three-slot form (Llama-2-7B, K = 11008) still loses (6.02 vs 6.30 us) and stays a profiling knob.
+        if (!shared) return false;
     } else if (g_engine != 8) return false;
     const int sh = divUp(a.ku, 64);
     const bool shape = shared ? (sh == 4 && a.ku - (sh - 1) * 64 <= 32) : (sh == 3 && a.ku - (sh - 1) * 64 > 32);
