@@ -70,9 +70,16 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched without torch.distributed.run: this process becomes the launcher of --gpus replicas of itself (replicas only,
+        # SURVEY 8e; llama2_q4.cu:465-482 is why), rank 0 prints the line. On a box with fewer GPUs q4_set_device fails loudly.
+        from llama_cu_awq_amd import replicas
+        sys.exit(replicas.spawn(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and (world > 1 or args.gpus > 1):
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE %d: the launcher's world size is what runs\n" % (args.gpus, world))
     use_dist = world > 1 or args.force_dist
 
     # N > 1: torch (its bundled HIP runtime) must be initialised BEFORE libllama2_q4.so is loaded -- both export

@@ -91,6 +91,7 @@ struct Handoff {
     unsigned dead;         // the error word as read at entry, kept raw (arithmetic on it at entry would pull the load's wait there).
                            // != 0: an earlier launch timed out and the host has not cleared the state yet -- results are void anyway,
                            // so nobody spins again: a long queue of launches behind a failure drains at once
+    unsigned long long hold_until;   // consumer: wall clock (100 MHz) before which the role does not request its weights, or 0 (layer_attn.h: split-context forms)
     bool mute;             // profiling build: this attention block does not publish (provokes a real time-out, tests/prof_cases.py)
     unsigned long long* stamp;   // profiling build: wall clock right after the wait
 };
@@ -325,6 +326,9 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         }                                                                                                         \
     }
 #define Q4_ISSUE_ANY(s) { if (HALF && (s) == SLOTS - 1) Q4_ISSUE_HALF() else Q4_ISSUE_SLOT(s) }
+    if (ROLE == ROLE_CONSUMER) {   // held back while the producers' stream needs the memory system for itself (layer_attn.h)
+        if (ho.hold_until != 0ull) while (wall_clock64() < ho.hold_until) __builtin_amdgcn_s_sleep(4);
+    }
 #pragma unroll
     for (int s = 0; s < PRE; s++) Q4_ISSUE_ANY(s)
     __builtin_amdgcn_sched_barrier(0);

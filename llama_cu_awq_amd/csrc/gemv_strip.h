@@ -14,19 +14,9 @@
 //   MODE 2: MODE 1 with the dealing order rotated by eight waves: the waves that do not stage x take the longer share.
 #pragma once
 #include "gemv_q4.h"
+#include "lds_dma.h"
 
 namespace q4 {
-
-// one LDS-DMA piece: 64 lanes x 16 B from (descriptor, soffset + lane * 16) to LDS bytes [lds_dst, lds_dst + 1024).
-// M0 (the LDS destination) is written in the statement that uses it; hipcc neither counts these loads nor waits for them.
-__device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Flag words in LDS. A wave's LDS operations execute in program order, so "write data, then bump the flag" and "see the flag, then
 // read data" need no hardware fence inside a workgroup; the relaxed forms + compiler barriers keep hipcc from re-ordering them AND
@@ -79,7 +69,6 @@ struct StripLds {
     static constexpr unsigned BYTES = FLAGS + 64u;
 };
 enum { SF_SS = 0, SF_STAGED = 1, SF_FAIL = 2 };
-__device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // stamps (tools/timeline_strip.py; kept in LDS and written out at the end: a global store would count in vmcnt): [0] wave 0 entry,
 // [1] its x landed, [2] sum of squares exchanged, [3] x staged, [4 + i] its unit i multiplied, [12] its totals written, [13] outputs

@@ -13,6 +13,12 @@ static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->z
 
 int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention blocks of the next n launches do not publish
 int g_ao_vslice = 1;  // below the split-context bins: head_size / 32 attention blocks per head, one 64-byte V slice each (0: one block)
+int g_att_ring = 0;   // profiling knob 14: the split-context attention role takes its K / V rows on LDS-DMA rings (same bits, same speed: DESIGN.md)
+// split-context bins: the o-proj role requests its weights after this share of the K / V stream's estimated duration (0: at entry). -1 = the measured
+// optimum per bin (tools/sweep_attn_hold.py, 7B, ms per token inside the bin, hold 0 / 100 / 140 / 180 %: bin 512 1.0933 / 1.0777 / 1.0710 / 1.0807,
+// bin 1024 1.1229 / 1.1120 / 1.1255 / 1.1334, bin 2048 1.1925 / 1.1812 / 1.1979 / 1.2147)
+int g_ao_hold_pct = -1;
+static int ao_hold_pct(int seq_len_bin) { return g_ao_hold_pct >= 0 ? g_ao_hold_pct : seq_len_bin <= 512 ? 140 : 100; }
 int g_ao_guard = 1;   // profiling build: q4_set_gemv_early(8, 0) admits grids larger than the resident capacity (forward-progress tests)
 
 // CUs the launch stream may use: all of the device, or the bits of its CU mask (hipExtStreamCreateWithCUMask)
@@ -60,7 +66,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     const int nsp = divUp(seq_len_bin, chunk);
     const bool split = seq_len_bin >= split_min && have_scratch && n_heads <= SYNC_MAX_HEADS &&
                        (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(u32x2v) <= scratch_bytes;   // records as {float, tag} granules
-    if (split) { s.att = chunk == 64 ? 4 : chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
+    if (split) { s.att = (chunk == 64 ? 4 : chunk == 128 ? 2 : 3) + (g_att_ring ? 5 : 0); s.nsp = nsp; return s; }   // (7 / 8 / 9: K / V rows on LDS-DMA rings)
     if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return s;
     s.att = seq_len_bin <= 128 ? 0 : 1;
     // (only where the bin is one register-resident group of the role, <= 256 positions: a model whose scratch does not hold
@@ -71,7 +77,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
 
 static size_t ao_smem(const AoShape& s, int head_size, int seq_len_bin) {
     const size_t smem_gemv = (size_t)s.slots * 256 * 16 + (size_t)s.slots * 512 + (size_t)s.slots * 256 * 4 + 16;
-    const size_t smem_att = s.att >= 2 && s.att <= 4 ? (size_t)(32 + LA_WAVES * head_size) * 4 : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem_att = att_is_split(s.att) ? att_split_lds_bytes(LA_WAVES, head_size, att_ring(s.att)) : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
     return smem_gemv > smem_att ? smem_gemv : smem_att;
 }
 
@@ -80,7 +86,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     const AoShape s = ao_shape(dim, kv_dim, head_size, n_heads, seq_len_bin, have_scratch, scratch_bytes, split_min, split_chunk);
     if (s.att < 0) return -1;
     const size_t smem = ao_smem(s, head_size, seq_len_bin);
-    if (smem > 64 * 1024) return -1;
+    if (smem > AO_LDS_MAX) return -1;
     // Residency guard. Only the o-proj blocks wait, and only for attention blocks, which wait for nobody. Whatever order the
     // dispatcher picks, the launch cannot wedge as long as the waiting blocks alone cannot fill the stream's CUs: a slot is then
     // always left for an attention block, and every attention block that runs ends. (All blocks resident at once is the common
@@ -96,7 +102,7 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
     }
     const int per_cu = it->second;
     // (split-context forms: the head's first chunk block waits for the other chunks' records -- one more waiter per head)
-    const long long waiters = dim / (LA_WAVES * la_ocols(s.slots)) + (s.att >= 2 && s.att <= 4 ? n_heads : 0);
+    const long long waiters = dim / (LA_WAVES * la_ocols(s.slots)) + (att_is_split(s.att) ? n_heads : 0);
     if (g_ao_guard && (long long)per_cu * stream_cu_count() < waiters + 1) return -1;
     return s.att;
 }
@@ -121,13 +127,19 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.nheads = n_heads;
     a.natt = n_heads * s.nsp;
     a.no = dim / (LA_WAVES * la_ocols(s.slots));
+    if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0) {
+        // K and V rows of one position: 2 x kv_dim halves; the stream moves at ~5.9 TB/s (measured, tools/timeline_split.py); 10 ns ticks, Q16
+        const double ticks_per_pos = (4.0 * kv_dim) / 5.9e12 * 1e8;
+        a.hold_q16 = (unsigned)(ticks_per_pos * 65536.0 * ao_hold_pct(seq_len_bin) / 100.0);
+    }
 #ifdef Q4_PROFILING
     a.att.dbg = g_dbg ? g_dbg + 4096 * 4 : nullptr;      // per-wave cycle stamps of the attention role, behind the per-block records
+    a.split.dbg = a.att.dbg;                             // (split-context forms: wall-clock stamps, same place)
     a.dbg = g_dbg;
     if (g_ao_mute > 0) { a.mute = 1; g_ao_mute--; }
 #endif
     const size_t smem = ao_smem(s, head_size, seq_len_bin);
-    if (smem > 64 * 1024) return Q4_ERR_UNSUPPORTED_SIZE;
+    if (smem > AO_LDS_MAX) return Q4_ERR_UNSUPPORTED_SIZE;
     return s.launch(s.slots_kind, s.att, dim3(a.natt + a.no), dim3(LA_WAVES * 64), smem, a, nullptr);
 }
 

@@ -98,6 +98,8 @@ extern int g_att_chunk;
 extern int g_att_split_min;
 extern int g_ao_guard;
 extern int g_ao_vslice;
+extern int g_att_ring;
+extern int g_ao_hold_pct;
 extern int g_multi_steps;
 extern int g_engine;        // gemv_engine.hip
 #ifdef Q4_PROFILING

@@ -288,6 +288,8 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 7) g_multi_steps = slots;
     if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
+    if (kind == 15) g_ao_hold_pct = slots;  // split-context bins: the o-proj role's weight requests held back this share of the K / V stream's estimated duration
+    if (kind == 14) g_att_ring = slots;     // 0: the split-context attention role takes its K / V rows in registers, 1: on LDS-DMA rings (same bits)
     if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
     if (kind == 11) g_engine = slots;       // the GEMV forms: 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings (gemv_engine.hip)
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)

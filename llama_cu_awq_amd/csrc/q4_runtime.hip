@@ -348,7 +348,14 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         if (pass == 1) {
             if (hipMalloc(&slabs.state, sd.off) != hipSuccess) { printf("malloc failed for allocaing run state!\n"); rc = Q4_ERR_ALLOC; break; }
             cur = {(char*)slabs.state, 0};
-            hipMemset(slabs.state, 0, sd.off);
+            // zeroed on the launch stream and waited for: a null-stream hipMemset returns before the device has finished, and nothing orders it
+            // before the first launches on a non-blocking g_stream -- a small model's first K / V rows could be zeroed AFTER they were written
+            if (hipMemsetAsync(slabs.state, 0, sd.off, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                hipDeviceSynchronize();
+                hipMemset(slabs.state, 0, sd.off);
+                hipDeviceSynchronize();
+            }
         }
         s->x = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));
         s->xb = (q4_half*)c.take((size_t)p->dim * sizeof(q4_half));

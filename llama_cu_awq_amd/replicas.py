@@ -23,3 +23,49 @@ def aggregate(elapsed_s, tokens, dist=None, device="cpu"):
     k = torch.tensor([float(tokens)], dtype=torch.float64, device=device)
     dist.all_reduce(k, op=dist.ReduceOp.SUM)
     return float(t.item()), int(round(k.item()))
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn(n, argv, env=None, timeout=None):
+    """Launch `n` replica processes of the command `argv` (one per GPU of this node) with the torch.distributed environment a
+    launcher would give them -- RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port -- and wait for all
+    of them. HIP_VISIBLE_DEVICES is left alone: every replica selects its own GPU by LOCAL_RANK (q4_set_device), so a box with fewer
+    than `n` GPUs fails loudly there. Rank 0's stdout is this process's stdout (the one JSON line of bench.py); the other ranks'
+    stdout goes to stderr. Returns the largest exit code; a replica that fails ends the others."""
+    import os
+    import subprocess
+    import sys
+    import time
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base["MASTER_PORT"] = str(free_port())
+    base["WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+    t0 = time.time()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0:
+                rc = max(rc, c if c > 0 else 1)
+                for o in live:          # a failed replica would leave the others in the barrier for ever
+                    procs[o].terminate()
+        if timeout is not None and time.time() - t0 > timeout:
+            for o in live:
+                procs[o].kill()
+            return max(rc, 124)
+        time.sleep(0.05)
+    return rc

@@ -414,3 +414,39 @@ def test_qkv_strips_equal_the_wave_owned_kernel(q4, tmp_path, model, steps, fusi
         for (pos, lg, k, v), (_, lg0, k0, v0) in zip(outs[engine][0], outs[-1][0]):
             assert np.array_equal(k, k0) and np.array_equal(v, v0), (engine, pos, "KV rows")
             assert np.array_equal(lg, lg0), (engine, pos, "logits")
+
+
+@pytest.mark.parametrize("model,steps", [("head128", 1090), ("head128_gqa", 690), ("head64_long", 1290), ("head256", 590), ("tinyllama", 1090),
+                                         ("long16k_h128", 4200)])
+def test_kv_rings_of_the_split_context_attention_role_are_bit_neutral(q4, model, steps):
+    """Split-context bins of the attention -> o-proj launch (round 5): knob 14 = 1 brings a chunk block's K / V rows in on
+    per-wave LDS-DMA rings (csrc/attention.h, RING), 0 (the product) in registers. Same lanes, same bytes, same order of every sum: logits and token
+    rings must be equal BIT FOR BIT at every checkpoint, through bins 512 (64-position chunks), 1024 (128), 2048 and up (256), heads of
+    64 / 128 / 256, multi-head and grouped-query."""
+    L = q4.lib()
+    path = _model_file(model)
+    cps = sorted({511, 512, 513, 600, 1023, 1024, 1030, 2047, 2048, 2100, 4096, 4100, steps - 1} & set(range(steps)))
+    outs = {}
+    timeouts = L.q4_handoff_timeouts()
+    try:
+        for run, knob in enumerate((0, 1, 0)):       # (the third run is the control: the register form against itself)
+            L.q4_set_gemv_early(14, knob)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in cps:
+                    q4.synchronize()
+                    got.append(t.logits().view(np.uint16).copy())
+            q4.check(L.q4_handoff_status(t.state))
+            assert L.q4_handoff_timeouts() == timeouts
+            outs[run] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            t.close()
+    finally:
+        L.q4_set_gemv_early(14, 0)
+    for a, b, pos in zip(outs[0][0], outs[2][0], cps):
+        assert np.array_equal(a, b), "control: the register form differs from itself at position %d" % pos
+    assert outs[0][1] == outs[1][1], "token rings differ"
+    for a, b, pos in zip(outs[0][0], outs[1][0], cps):
+        assert np.array_equal(a, b), "ring form differs from the register form at position %d" % pos

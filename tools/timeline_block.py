@@ -26,6 +26,9 @@ L.q4_set_stream(s)
 L.q4_set_fusion(fusion)
 if len(sys.argv) > 5:      # split-context setting: positions per block, smallest bin that splits
     L.q4_set_attention_split(int(sys.argv[4]), int(sys.argv[5]))
+for kv in os.environ.get("KNOBS", "").split(","):      # profiling knobs, e.g. KNOBS=14=0 (the split-context role's K / V rows in registers)
+    if kv:
+        L.q4_set_gemv_early(int(kv.split("=")[0]), int(kv.split("=")[1]))
 tr = api.Transformer(path)
 tr.generate_ids([1, 2436, 385, 3686, 388, 1048, 22796, 118], upto)
 L.q4_set_use_graphs(0)
