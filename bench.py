@@ -54,6 +54,36 @@ def kernel_bytes(cfg):
     }
 
 
+def sample_sclk_ghz(run, seconds=2.5):
+    """Shader clock while `run()` keeps the token loop busy: rocm-smi polled from a side thread (the timed region is never sampled: the
+    poll costs host time). Returns (GHz, source); without rocm-smi the 2.35 GHz of tools/clock_probe.sh (round 4: 2325-2364 MHz in the loop)."""
+    import re
+    import subprocess
+    import threading
+    vals, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                mm = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", out)
+                if mm:
+                    vals.append(int(mm.group(1)))
+            except Exception:
+                return
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        run()
+    stop.set()
+    th.join(timeout=15)
+    vals = [v for v in vals if v > 500]
+    if vals:
+        return max(vals) / 1000.0, "rocm-smi --showclocks during the token loop (%d samples, max of %s MHz)" % (len(vals), sorted(set(vals)))
+    return 2.35, "tools/clock_probe.sh, round 4: sclk 2325-2364 MHz in the token loop (rocm-smi not usable here)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +97,8 @@ def main():
     ap.add_argument("--f64-steps", type=int, default=10, help="positions of the unrounded double forward used as parity yardstick")
     ap.add_argument("--force-dist", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (13B -n 256, 7B -n 2048)")
-    ap.add_argument("--no-graphs", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes inside hipGraph capture)")
+    ap.add_argument("--no-graphs", action="store_true", help="eager launches with the graph path's sequence-length bins: what the graphs run, one launch "
+                                                               "at a time (rocprofv3 kernel tracing crashes inside hipGraph capture)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -107,7 +138,7 @@ def main():
     L = api.lib()
     api.check(L.q4_set_device(local_rank if world > 1 else 0))
     if args.no_graphs:
-        L.q4_set_use_graphs(0)
+        L.q4_set_use_graphs(2)
 
     def barrier():
         api.check(L.q4_device_synchronize())
@@ -195,7 +226,7 @@ def main():
         # tracer). The line takes the LARGER of the two, so it never claims more than the committed profile supports; the
         # per-launch cost inside a hipGraph (kernel + boundary) is reported next to it.
         rocprof_us, rocprof_src = None, None
-        for tag in ("r04", "r03", "r02"):
+        for tag in ("r05", "r04", "r03", "r02"):
             cpath = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s_%d_eager.csv" % (tag, args.model, ntok))
             if os.path.exists(cpath):
                 import csv
@@ -231,7 +262,7 @@ def main():
                                 "frac": round(kb[0][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
         traffic, traffic_src = None, None
         # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
-        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.model == "7b":
                 tj_all = json.load(open(tpath))
@@ -264,18 +295,23 @@ def main():
                                     "graph over the ring of the layers' weights, kernel + boundary",
                     "isolated_ring_us": kernels[kb[0][0]]["us"],
                     "per_kernel": per_kernel}
-        # what else bounds the kernel: the committed SQ counters of the same launch (tools/profile_sq.sh). The int4 dequant-dot is
-        # VALU work: the pipes are busy for most of the launch, which is why bytes-in-flight experiments never paid
-        for tag in ("r04",):
+        # what else bounds the kernel: the committed SQ counters of the same launch (tools/profile_sq.sh), priced at the shader clock read
+        # from rocm-smi while the token loop runs. The int4 dequant-dot keeps the VALU pipes busy for 0.43-0.48 of the launch: not the bound
+        for tag in ("r05", "r04"):
+            if "valu" in roofline:
+                break
             sq_path = os.path.join(ROOT, "profiles", "%s_sq_counters_gate_up.json" % tag)
             if os.path.exists(sq_path) and args.model == "7b":
                 sq = json.load(open(sq_path))
-                clock_ghz = 2.1       # shader clock under this load (s_memtime against the 100 MHz wall clock, tools/timeline.py)
+                clock_ghz, clock_src = sample_sclk_ghz(lambda: tr.generate_ids(PROMPT_IDS, ntok))   # shader clock under this load
                 busy_us = sq.get("valu_busy_cycles_per_simd", 0.0) / (clock_ghz * 1e3)
                 roofline["valu"] = {"instructions_per_launch": sq.get("SQ_INSTS_VALU"), "instructions_per_wave": sq.get("valu_instructions_per_wave"),
                                     "cycles_per_instruction": sq.get("cycles_per_valu_instruction"),
-                                    "busy_cycles_per_simd": sq.get("valu_busy_cycles_per_simd"), "busy_us_at_2.1GHz": round(busy_us, 2),
+                                    "busy_cycles_per_simd": sq.get("valu_busy_cycles_per_simd"), "sclk_GHz": round(clock_ghz, 3), "sclk_source": clock_src,
+                                    "busy_us": round(busy_us, 2),
                                     "busy_fraction_of_launch": round(busy_us / dom["us"], 3),
+                                    "reading": "the VALU pipes are busy for less than half of the launch: the gate/up kernel is bounded by first-data latency + "
+                                               "the x chain + the tail of its stream, not by VALU issue (DESIGN.md)",
                                     "source": "profiles/%s_sq_counters_gate_up.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ...)" % tag}
         kernels["in_network_us"] = in_network
         int4_bytes = sum(kb[k][1] for k in (0, 2, 3, 4))
@@ -368,10 +404,21 @@ def main():
                 synth.write_model(p2, g2)
             t2 = api.Transformer(p2, temperature=0.0)
             t2.generate_ids(PROMPT_IDS, n)                       # warm + graph capture of every bin
-            best = max(t2.generate_ids(PROMPT_IDS, n)[1] for _ in range(2))
+            runs = [t2.generate_ids(PROMPT_IDS, n) for _ in range(2)]
+            best = max(r[1] for r in runs)
             gb = GB_PER_TOKEN[(mname, n)]
             extra["llama2_%s_n%d" % (mname, n)] = {"tokens_per_s": round(best, 1), "ms_per_token": round(1000.0 / best, 4), "GB_per_token": gb,
                                                     "frac_of_8TBps": round(best * gb / HBM_PEAK_GBS, 4)}
+            if n == 2048:
+                # the KV-stress regime alone: positions 1024..2047 (the last sequence-length bin), from the difference of two generations'
+                # wall times; bytes per token there = weights + K and V rows of 1536.5 positions on average
+                half = min(t2.generate_ids(PROMPT_IDS, 1024)[3] for _ in range(2))
+                full = min(r[3] for r in runs)
+                tps_hi = 1024.0 / (full - half)
+                kv_dim2 = g2[0] * g2[4] // g2[3]
+                gb_hi = (3627302912 + 2 * g2[2] * 1536.5 * kv_dim2 * 2) / 1e9
+                extra["llama2_%s_n%d" % (mname, n)]["positions_1024_2047"] = {"tokens_per_s": round(tps_hi, 1), "ms_per_token": round(1000.0 / tps_hi, 4),
+                                                                              "GB_per_token": round(gb_hi, 3), "frac_of_8TBps": round(tps_hi * gb_hi / HBM_PEAK_GBS, 4)}
             if mname == "13b":
                 # the 13B launches by HIP events inside the eager network, like roofline.per_kernel above (gate/up and the down projection run as
                 # strips there: csrc/gemv_strip.h, gemv_strip_down.h)
@@ -391,6 +438,28 @@ def main():
                               "frac": round(kb2[kid][1] / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_}
                 extra["llama2_%s_n%d" % (mname, n)]["per_kernel"] = pk
             t2.close()
+        # the reference CLI's DEFAULT mode (-t 0.5 -p 0.6, llama2_q4.cu:632-633: temperature / top-p sampling inside the captured graphs,
+        # csrc/q4_sampling.hip) on the headline geometry, and the grouped-query geometry of Mistral-7B (llama2_q4.cu:309-313), greedy
+        t3 = api.Transformer(path, temperature=0.5, topp=0.6, seed=20240229)
+        t3.generate_ids(PROMPT_IDS, ntok)
+        r3 = [t3.generate_ids(PROMPT_IDS, ntok) for _ in range(2)]
+        b3 = max(r3, key=lambda r: r[1])
+        extra["llama2_7b_n256_t0.5_p0.6"] = {"tokens_per_s": round(b3[1], 1), "ms_per_token": round(1000.0 / b3[1], 4), "timed_tokens": int(b3[2]),
+                                              "GB_per_token": GB_PER_TOKEN[("7b", 256)], "frac_of_8TBps": round(b3[1] * GB_PER_TOKEN[("7b", 256)] / HBM_PEAK_GBS, 4),
+                                              "sampler": "temperature 0.5, top-p 0.6, seed 20240229 (a sampled EOS ends a generation early: timed_tokens)"}
+        t3.close()
+        g4 = synth.GEOMETRIES["mistral7b"]
+        p4 = os.path.join(args.model_dir, "llama2_q4_synth_mistral7b_seed20240229.bin")
+        if not (os.path.exists(p4) and os.path.getsize(p4) == synth.model_bytes(g4)):
+            synth.write_model(p4, g4)
+        t4 = api.Transformer(p4, temperature=0.0)
+        t4.generate_ids(PROMPT_IDS, 256)
+        b4 = max(t4.generate_ids(PROMPT_IDS, 256)[1] for _ in range(2))
+        kv4 = g4[0] * g4[4] // g4[3]
+        gb4 = (synth.model_bytes(g4) - 32 - g4[5] * g4[0] * 2 + 2 * g4[2] * 128.5 * kv4 * 2) / 1e9     # weights without the embedding table + average K / V rows
+        extra["mistral7b_n256"] = {"tokens_per_s": round(b4, 1), "ms_per_token": round(1000.0 / b4, 4), "GB_per_token": round(gb4, 3),
+                                   "frac_of_8TBps": round(b4 * gb4 / HBM_PEAK_GBS, 4), "geometry": "dim 4096, hidden 14336, 32 layers, 32 heads / 8 kv heads"}
+        t4.close()
         tr = api.Transformer(path, temperature=0.0)
 
     if rank == 0:
@@ -404,7 +473,6 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Llama-2-%s AWQ w4 g128 (synthetic weights, real geometry), -n %d greedy, 8-token prompt, "
                                    "%d timed tokens per step" % (args.model.upper(), ntok, timed_tokens // max(args.steps, 1)),
-                       "dim": cfg.dim, "hidden_dim": cfg.hidden_dim, "n_layers": cfg.n_layers, "vocab_size": cfg.vocab_size,
                        "parallelism": "replicas x%d (no data-path collective)" % world},
             "ms_per_token": round(1000.0 * elapsed * world / max(total_tokens, 1), 4),
             "whole_token": {"GB_per_token": GB_PER_TOKEN.get((args.model, ntok)), "frac_of_8TBps": round(value / max(world, 1) * GB_PER_TOKEN[(args.model, ntok)] / HBM_PEAK_GBS, 4)

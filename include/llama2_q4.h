@@ -236,7 +236,9 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * time-outs), then tries level 3 again; q4_set_fusion(3) re-arms it at once. Resets captured graphs. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
-/* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches */
+/* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches with the exact context length (the
+ * reference's other path, :374); 2: eager launches with the graph path's sequence-length bin -- exactly what the graphs run, one launch
+ * at a time (the mode to profile in: rocprofv3 cannot trace inside a graph capture) */
 void q4_set_use_graphs(int enable);
 void q4_reset_graphs(void);   /* drop captured graphs (main() cleanup llama2_q4.cu:713-716) */
 

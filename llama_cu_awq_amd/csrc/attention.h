@@ -434,149 +434,36 @@ __device__ __forceinline__ void split_store_record(const SplitArgs& a, const Han
 }
 
 // PUB: the merged output also leaves as data-tagged granules for the o-proj blocks of the same launch (layer_attn.hip)
-// RING > 0: the K / V rows arrive through LDS instead of registers (lds_dma.h). Every wave owns a private ring of RING 1 KiB pieces at
-// the front of the block's LDS; piece j < U is the wave's K-row instruction j (64 / LPR rows x 16 B x LPR lanes: lane l's 16 bytes land
-// at byte l * 16 of the piece), piece U + j its V-row instruction j. min(RING, 2 U) pieces go out at entry behind q; the wave waits for
-// its oldest piece with vmcnt, reads its own 16 bytes back with one ds_read_b128, re-issues the entry and multiplies -- the V pieces
-// land while the scores, the block maximum and the exponentials run. The SAME lanes see the SAME bytes and add the SAME terms in the
-// same order as the register form (RING = 0): bit-identical records, only the way in differs (a CU's vector-memory path delivers
-// ~22 GB/s into registers and 31-32 GB/s into LDS). Block LDS: [NW x RING KiB rings][red_max 16][red_sum 16][outp].
 constexpr size_t att_split_lds_bytes(int nw, int head_size, int ring) { return (size_t)nw * ring * 1024 + (size_t)(32 + nw * head_size) * 4; }
-template <int LPR, int U, bool PUB, int NW = ATT_NW, int RING = 0>
-__device__ __forceinline__ void attention_split_body(const SplitArgs& a, const int h, const int sp, const int nsp, const Handoff& ho) {
-    float* partials = a.partials;
-    const q4_half* q = a.q;
-    const q4_half* key_cache = a.key_cache;
-    const q4_half* value_cache = a.value_cache;
-    const int head_size = a.head_size, kv_mul = a.kv_mul, kv_dim = a.kv_dim;
-    const int* pPos = a.pPos;
-    const float alpha = a.alpha;
-    q4_half* output = a.output;
-    unsigned* arrive = a.arrive;
-    constexpr int R = 64 / LPR;
-    constexpr int stride = NW * R;
-    constexpr int ATT_CHUNK = stride * U;                    // positions per block = one register-resident group
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr unsigned RING_BYTES = (unsigned)NW * RING * 1024u;
+// How a live chunk block takes its K / V rows in: the product reads them into registers (every row requested at entry, one memory latency for the
+// chunk). exp/attention_ring.h (laboratory) brings them in on per-wave LDS-DMA rings instead: same lanes, same bytes, same sums, same speed.
+struct KvInRegisters { static constexpr unsigned ring_bytes(int) { return 0u; } };
+
 #ifdef Q4_PROFILING
-    // [0] entry, [1] position known, [2] q landed, [3] scores done, [4] block maximum known, [5] P.V done, [6] record stored, [7] head merged (chunk 0)
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// per-wave wall-clock stamps (tools/timeline_split.py): [0] entry, [1] position known, [2] q landed, [3] scores done, [4] block maximum known,
+// [5] P.V done, [6] record stored, [7] head merged (chunk 0)
 #define SPLIT_STAMP(k) do { if (a.dbg) ts[(k)] = wall_clock64(); } while (0)
 #define SPLIT_STAMP_PIN(k, v) do { if (a.dbg) { asm volatile("" : "+v"(v)); ts[(k)] = wall_clock64(); } } while (0)
 #else
 #define SPLIT_STAMP(k) do { } while (0)
 #define SPLIT_STAMP_PIN(k, v) do { } while (0)
 #endif
-    SPLIT_STAMP(0);
-    float* red_max = reinterpret_cast<float*>(smem + RING_BYTES);
-    float* red_sum = red_max + 16;
-    float* outp = red_sum + 16;                              // [NW][head_size]
-    __shared__ int is_last;
+
+// one live chunk: scores, the chunk's maximum, exp, P.V, the flash-decode record (acc[head_size], m, l) -- attention_split_body's middle
+template <int LPR, int U, bool PUB, int NW>
+__device__ __forceinline__ void split_live(KvInRegisters, const SplitArgs& a, const Handoff& ho, const int h, const int sp, const int nsp, const int size, const int t_base,
+                                           float* red_max, float* red_sum, float* outp, unsigned long long* ts) {
+    constexpr int R = 64 / LPR;
+    constexpr int stride = NW * R;
+    const q4_half* q = a.q;
+    const q4_half* key_cache = a.key_cache;
+    const q4_half* value_cache = a.value_cache;
+    const int head_size = a.head_size, kv_mul = a.kv_mul, kv_dim = a.kv_dim;
+    const float alpha = a.alpha;
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = tid >> 6;
     const int row = lane / LPR, sub = lane % LPR;
-    const int size = __builtin_amdgcn_readfirstlane(*pPos) + 1;
-    SPLIT_STAMP(1);
-    const int t_base = sp * ATT_CHUNK;
-    const int rec = head_size + ATT_REC_PAD;
-    float* my = partials + ((size_t)h * nsp + sp) * rec;
-    const bool live = t_base < size;                         // chunk entirely in the future: neutral partial (m = -inf, l = 0)
-    if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
-    if constexpr (RING > 0) { if (live) {
-        constexpr int T = 2 * U;                             // pieces of a wave: K-row instructions, then V-row instructions
-        constexpr int D = RING < T ? RING : T;               // in flight at most
-        static_assert(D <= 16, "vmcnt waits are constants up to 15");
-        const unsigned row_bytes = (unsigned)kv_dim * 2u;
-        const unsigned lane_off = ((unsigned)(h / kv_mul) * (unsigned)head_size + (unsigned)sub * 8u) * 2u;
-        const unsigned off_last = (unsigned)(size - 1) * row_bytes + lane_off;           // rows past the position: the last row, masked below
-        const unsigned off0 = (unsigned)(t_base + wave * R + row) * row_bytes + lane_off;
-        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)key_cache, 0, (unsigned)size * row_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)value_cache, 0, (unsigned)size * row_bytes, 0x00020000);
-        const unsigned wave_s = (unsigned)__builtin_amdgcn_readfirstlane(wave);            // (M0 is written from an SGPR)
-        const unsigned ring = (unsigned)(uintptr_t)smem + wave_s * (RING * 1024u);
-        auto issue = [&](int j) {                            // (j is a constant at every call site once unrolled)
-            const unsigned off = off0 + (unsigned)((j < U ? j : j - U) * stride) * row_bytes;
-            dma_piece(ring + (unsigned)(j % D) * 1024u, off < off_last ? off : off_last, j < U ? rk : rv, 0u);
-        };
-        // request order = arrival order: q, then the ring. q by an asm load: hipcc must not count it (it cannot see the pieces behind it)
-        u32x4 qv;
-        {
-            const u32x4* pq = reinterpret_cast<const u32x4*>(q + (size_t)h * head_size + sub * 8);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(qv) : "v"(pq) : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < D; j++) issue(j);
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qv) : "n"(D) : "memory");               // all but the ring: q has landed
-        SPLIT_STAMP(2);
-        const unsigned char* rbase = smem + wave_s * (RING * 1024u) + lane * 16u;
-        float sc[U];
-        float wmax = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            constexpr int DM1 = D - 1;
-            wait_vmcnt_upto15(T - 1 - u < DM1 ? T - 1 - u : DM1);                        // piece u has landed
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(rbase + (u % D) * 1024);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // read: the entry may be refilled
-            if (u + D < T) issue(u + D);
-            const int t = t_base + wave * R + row + u * stride;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) s = __builtin_amdgcn_fdot2(as_h2(kv[e]), as_h2(qv[e]), s, false);
-            s = row_sum<LPR>(s);
-            s = round_h(s * alpha);
-            sc[u] = t < size ? s : -INFINITY;
-            wmax = fmaxf(wmax, sc[u]);
-            asm volatile("" : "+v"(wmax), "+v"(sc[u]));      // the piece's arithmetic stays in front of the next piece's wait
-        }
-        wmax = wave_max(wmax);
-        SPLIT_STAMP_PIN(3, wmax);
-        if (lane == 0) red_max[wave] = wmax;
-        block_barrier_lds();
-        float m = row16_max(red_max[lane & 15]);
-        SPLIT_STAMP_PIN(4, m);
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] = 0.f;
-        float lsum = 0.f;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            constexpr int DM1 = D - 1;
-            const float p = expf(sc[u] - m);                 // 0 for masked positions (sc = -inf)
-            if (sub == 0) lsum += p;
-            wait_vmcnt_upto15(U - 1 - u < DM1 ? U - 1 - u : DM1);                        // piece U + u has landed
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(rbase + ((U + u) % D) * 1024);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (U + u + D < T) issue(U + u + D);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const h2 v2 = as_h2(vv[e]);
-                acc[2 * e] = __builtin_fmaf((float)v2.x, p, acc[2 * e]);
-                acc[2 * e + 1] = __builtin_fmaf((float)v2.y, p, acc[2 * e + 1]);
-            }
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
-        }
-        SPLIT_STAMP_PIN(5, acc[0]);
-        lsum = wave_sum(lsum);
-        if (lane == 0) red_sum[wave] = lsum;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float v = acc[e];
-            if (LPR <= 32) v += __shfl_xor(v, 32);
-            if (LPR <= 16) v += __shfl_xor(v, 16);
-            if (LPR <= 8) v += __shfl_xor(v, 8);
-            if (LPR <= 4) v += __shfl_xor(v, 4);
-            acc[e] = v;
-        }
-        if (lane < LPR) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) outp[wave * head_size + sub * 8 + e] = acc[e];
-        }
-        block_barrier_lds();
-        const float l = row16_sum(red_sum[lane & 15]);
-        split_store_record<PUB, NW>(a, ho, outp, m, l, h, sp, nsp);
-        SPLIT_STAMP(6);
-    } }
-    if (live) { if constexpr (RING == 0) {
+    {
         const q4_half* kh = key_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
         const q4_half* vh = value_cache + (size_t)(h / kv_mul) * head_size + sub * 8;
         // non-temporal: at these contexts the KV cache (>= 0.5 GB per token) does not stay in the 256 MB Infinity Cache;
@@ -653,7 +540,44 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
         const float l = row16_sum(red_sum[lane & 15]);
         split_store_record<PUB, NW>(a, ho, outp, m, l, h, sp, nsp);
         SPLIT_STAMP(6);
-    } } else if (PUB) {        // a chunk entirely in the future: the whole neutral record (m = -inf, l = 0, acc = 0), tagged
+    }
+}
+
+template <int LPR, int U, bool PUB, int NW = ATT_NW, typename LOAD = KvInRegisters>
+__device__ __forceinline__ void attention_split_body(const SplitArgs& a, const int h, const int sp, const int nsp, const Handoff& ho) {
+    float* partials = a.partials;
+    const int head_size = a.head_size;
+    const int* pPos = a.pPos;
+    q4_half* output = a.output;
+    unsigned* arrive = a.arrive;
+    constexpr int ATT_CHUNK = NW * (64 / LPR) * U;           // positions per block = one register-resident group
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr unsigned RING_BYTES = LOAD::ring_bytes(NW);      // (the laboratory's LDS-DMA rings lead the block's LDS; the product has none)
+#ifdef Q4_PROFILING
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    SPLIT_STAMP(0);
+    float* red_max = reinterpret_cast<float*>(smem + RING_BYTES);
+    float* red_sum = red_max + 16;
+    float* outp = red_sum + 16;                              // [NW][head_size]
+    __shared__ int is_last;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = tid >> 6;
+    (void)lane; (void)wave;                                  // (the stamped build writes per wave)
+    const int size = __builtin_amdgcn_readfirstlane(*pPos) + 1;
+    SPLIT_STAMP(1);
+    const int t_base = sp * ATT_CHUNK;
+    const int rec = head_size + ATT_REC_PAD;
+    float* my = partials + ((size_t)h * nsp + sp) * rec;
+    const bool live = t_base < size;                         // chunk entirely in the future: neutral partial (m = -inf, l = 0)
+    if (NW < 16 && tid >= NW && tid < 16) { red_max[tid] = -INFINITY; red_sum[tid] = 0.f; }   // the reductions read 16 entries
+    if (live) {
+#ifdef Q4_PROFILING
+        split_live<LPR, U, PUB, NW>(LOAD{}, a, ho, h, sp, nsp, size, t_base, red_max, red_sum, outp, ts);
+#else
+        split_live<LPR, U, PUB, NW>(LOAD{}, a, ho, h, sp, nsp, size, t_base, red_max, red_sum, outp, nullptr);
+#endif
+    } else if (PUB) {        // a chunk entirely in the future: the whole neutral record (m = -inf, l = 0, acc = 0), tagged
         if ((int)tid < rec) {
             u32x2v* g = reinterpret_cast<u32x2v*>(partials) + ((size_t)h * nsp + sp) * rec;
             store_granule(g + tid, (unsigned)as_i((int)tid == head_size ? -INFINITY : 0.f), ho.tag);

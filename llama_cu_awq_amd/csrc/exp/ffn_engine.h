@@ -1,6 +1,4 @@
-// gemv_engine.hip -- the gate/up launch's other forms. In the product: the dispatch to "strips" (gemv_strip.h, the form that ships for wide
-// matrices: ffn_engine_covers / launch_ffn_engine, called by launch_gemv_ffn). In the profiling build also an EXPERIMENT
-// (q4_set_gemv_early(11, 1..6)): the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows
+// exp/ffn_engine.h -- LABORATORY (libllama2_q4_prof.so only; knob 11 = 1..6). the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows
 // "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel +
 // ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit (tests/prof_cases.py compares the forms). The shipped library does
 // not contain the engine: measured on MI355X (profiles/r04_engine_records.txt) it lands the 47 MB in
@@ -32,17 +30,12 @@
 //            executed; the loader refills slot j % 8 when every read[w] >= j - 7 (a single running total would not do: the waves
 //            are not in lock step, four of them two slots ahead count like eight of them one slot ahead).
 //   consumer-only barriers of the x chain: one LDS counter each.
-#include "gemv_strip.h"   // the form that ships for wide matrices: no loader wave, every wave streams its own units (+ the LDS-DMA and LDS-flag helpers)
+#pragma once
+#include "../gemv_strip.h"
+#include "lds_flags.h"
 
 namespace q4 {
 
-int g_engine = 0;   // 0: the product's choice (gemv_strip.h: strips for wide matrices, gemv_q4_kernel<MODE_FFN> otherwise). Profiling build: -1 = gemv_q4_kernel
-                    // always; 1..3: the loader / consumer engine with LAG = value where the shape is covered (1 measured best); 5, 6 = LAG 1, 2 with the
-                    // consumers' next-slot prefetch; 8..14: a strips variant (8 also: every other strips form wherever its shape is covered -- down projection,
-                    // classifier, the 13B q/k/v launch of gemv_strip_qkv.h); 15: the product's gate/up choice without the down-projection strips; 19: the
-                    // product with K = 5120 gate/up on column units instead of pair units
-
-#ifdef Q4_PROFILING
 
 constexpr int ENG_CONSUMERS = 8, ENG_RING = 8, ENG_NQMAX = 14;   // 14 quads per CU: hidden_dim up to 14336 on 256 CUs
 
@@ -121,8 +114,8 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
         for (int m = 0; m < 2; m++) {
 #pragma unroll
             for (unsigned i = 0; i < L::SIDE_S_BYTES / 1024u; i++)
-                dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + i * 1024u, voff, rs[m], q0 * (128u * KSL) + i * 1024u);
-            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rz[m], q0 * (32u * KSL));
+                dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + i * 1024u, voff + i * 1024u, rsrc_from(a.m[m].s, q0 * (128u * KSL), (unsigned)(a.N * a.sh * 2)), 0u);
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES, voff, rsrc_from(a.m[m].z, q0 * (32u * KSL), (unsigned)(a.N * a.pzh * 4)), 0u);
         }
         ENG_STAMP(1);
         for (int j = 0; j < nq; j++) {
@@ -279,20 +272,15 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
 
 // the shapes the engine covers: K = 4096 (two 1 KiB k-slots per column), N in whole quads, at most ENG_NQMAX quads per CU
 // ... on a stream that may use every CU (one 147 KiB block per CU: on a CU-masked stream the blocks would queue behind each other)
-bool ffn_engine_covers(const GemvArgs& a) {
-    if (ffn_strip_covers(a)) return true;
-    return g_engine >= 1 && g_engine <= 7 && g_engine != 4 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
+static bool ffn_engine_covers(const GemvArgs& a) {
+    return g_gemv_form >= GEMV_ENGINE_LAG1 && g_gemv_form <= 7 && g_gemv_form != 4 && g_ablate == 0 && a.K == 4096 && (a.N & 3) == 0 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4 &&
            divUp(a.N >> 2, cu_count()) <= ENG_NQMAX && (a.N >> 2) >= cu_count() && stream_cu_count() == cu_count();
 }
 
 template <int KSL, bool NORM, int LAG, bool STAMPS, bool PF>
 static int launch_engine(const GemvArgs& a) {
-    static bool opted = false;
     constexpr size_t smem = EngLds<KSL>::BYTES;
-    if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)ffn_engine_kernel<KSL, NORM, LAG, STAMPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        opted = true;
-    }
+    { const int rc = lds_opt_in((const void*)ffn_engine_kernel<KSL, NORM, LAG, STAMPS, PF>, smem); if (rc) return rc; }
     const unsigned nquads = (unsigned)a.N >> 2, nb = (unsigned)cu_count();
     Q4_LAUNCH((ffn_engine_kernel<KSL, NORM, LAG, STAMPS, PF>), dim3(nb), dim3((ENG_CONSUMERS + 1) * 64), smem, a, nquads / nb, nquads % nb);
     Q4_LAUNCH_CHECK();
@@ -301,7 +289,7 @@ static int launch_engine(const GemvArgs& a) {
 
 template <bool NORM, bool STAMPS>
 static int launch_engine_lag(const GemvArgs& a) {
-    switch (g_engine) {        // + 4: WITH the next-slot prefetch (profiling build; measured slower: 10.2 against 9.7 us)
+    switch (g_gemv_form) {        // + 4: WITH the next-slot prefetch (profiling build; measured slower: 10.2 against 9.7 us)
         case 1: return launch_engine<2, NORM, 1, STAMPS, false>(a);
         case 2: return launch_engine<2, NORM, 2, STAMPS, false>(a);
         case 3: return launch_engine<2, NORM, 3, STAMPS, false>(a);
@@ -311,18 +299,10 @@ static int launch_engine_lag(const GemvArgs& a) {
     }
 }
 
-int launch_ffn_engine(const GemvArgs& a) {
-    if (ffn_strip_covers(a)) return launch_ffn_strip(a);
+static int launch_ffn_engine(const GemvArgs& a) {
     const bool norm = a.rms_w != nullptr;
     if (a.dbg) return norm ? launch_engine_lag<true, true>(a) : launch_engine_lag<false, true>(a);
     return norm ? launch_engine_lag<true, false>(a) : launch_engine_lag<false, false>(a);
 }
-
-#else    // the shipped library: strips where they pay, no loader / consumer engine
-
-bool ffn_engine_covers(const GemvArgs& a) { return ffn_strip_covers(a); }
-int launch_ffn_engine(const GemvArgs& a) { return launch_ffn_strip(a); }
-
-#endif
 
 }  // namespace q4

@@ -1,3 +1,4 @@
+// exp/qkv_strip.h -- LABORATORY (libllama2_q4_prof.so only; knob 11 = 8): bit-identical, measured slower than the wave-owned q/k/v kernel (EXPERIMENTS.md).
 // gemv_strip_qkv.h -- the fused q/k/v launch (rmsnorm_kernel + qkv_matvec_kernel + RoPERotation_kernel, gpu_kernels.h:72-105, 242-254, 332-355;
 // llama2_q4.cu:300, 307, 317) as strips, for the shape where gemv_q4.h's grid leaves the CUs uneven: Llama-2-13B (K = N = 5120: 960 four-wave blocks
 // = 3.75 per CU, the launch pays for four rows of blocks). Same scheme as gemv_strip.h -- one 16-wave block per CU, every wave streams its own units
@@ -18,7 +19,7 @@
 // projection's strips reach (144 KB in 8.4 us); that beat a K-split grid of 2.5 blocks per CU (10.5 us) and does not beat this launch's 3.75 blocks
 // per CU. Profiling build only, knob 11 = 8.
 #pragma once
-#include "gemv_strip.h"
+#include "../gemv_strip.h"
 
 namespace q4 {
 
@@ -236,9 +237,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) qkv_strip_kernel(const u32x4
 }
 
 // Llama-2-13B's shape: K = N = 5120 with the shared half slot, multi-head (N_kv = N), ten pairs per CU, the RoPE table of the model, on a stream
-// that may use every CU. Not the product's choice (measured slower, see the header): g_engine = 8 only (profiling build: strips wherever covered).
+// that may use every CU. Not the product's choice (measured slower, see the header): g_gemv_form = GEMV_STRIPS_EVERYWHERE only (profiling build: strips wherever covered).
 static bool qkv_strip_covers(const GemvArgs& a) {
-    if (g_engine != 8) return false;
+    if (g_gemv_form != GEMV_STRIPS_EVERYWHERE) return false;
     const int nb = cu_count();
     return strip_k5120(a) && a.nslots == 3 && half_tail(a) && a.N_kv == 0 && a.N == 2 * SQ_PAIRS * nb && a.rope && a.rope_table != nullptr && a.head_size >= 4 &&
            (a.head_size & 3) == 0 && a.N % a.head_size == 0 && a.pPos != nullptr && g_ablate == 0 && stream_cu_count() == nb;

@@ -1,21 +1,14 @@
 // gemv_ffn.hip -- instantiations of the int4 GEMV for ffn_matvec_silu_kernel (gpu_kernels.h:256-275)
 #include "gemv_q4.h"
 namespace q4 {
-bool ffn_engine_covers(const GemvArgs& a);   // gemv_engine.hip: loader / consumer form on LDS-DMA
-int launch_ffn_engine(const GemvArgs& a);
+bool ffn_strips_cover(const GemvArgs& a);   // gemv_ffn_strip.hip: the strips form (gemv_strip.h), for wide matrices
+int launch_ffn_strips(const GemvArgs& a);
 int launch_gemv_ffn(const GemvArgs& a, int cols, int waves) {
-    if (ffn_engine_covers(a)) return launch_ffn_engine(a);
+    if (g_lab.ffn_covers && g_lab.ffn_covers(a)) return g_lab.ffn_launch(a, waves);   // (null in the shipped library: q4_internal.h)
+    if (ffn_strips_cover(a)) return launch_ffn_strips(a);
 #define Q4_CASE(S, C) if (slots == S && cols == C) { \
         return a.rms_w ? launch_one<MODE_FFN, S, C, true>(a, waves) : launch_one<MODE_FFN, S, C, false>(a, waves); }
     const int slots = pick_slots(a.nslots);
-#ifdef Q4_PROFILING
-    if (g_ablate && slots == 2 && a.rms_w) {   // profiling-only ablations of the 7B gate/up kernel
-        if (g_ablate == 1) return launch_one<MODE_FFN, 2, 2, true, 1>(a, waves);
-        if (g_ablate == 2) return launch_one<MODE_FFN, 2, 2, true, 2>(a, waves);
-        if (g_ablate == 3) return launch_one<MODE_FFN, 2, 2, true, 3>(a, waves);
-        if (g_ablate == 4) return launch_one<MODE_FFN, 2, 2, true, 4>(a, waves);
-    }
-#endif
     if (slots == 3 && a.nslots == 3 && cols == 2 && half_tail(a))
         return a.rms_w ? launch_one<MODE_FFN, 3, 2, true, 0, 1, true>(a, waves) : launch_one<MODE_FFN, 3, 2, false, 0, 1, true>(a, waves);
     if (cols != 2 && cols != 4) cols = 2;

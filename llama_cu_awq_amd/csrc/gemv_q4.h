@@ -592,14 +592,8 @@ static int launch_one(const GemvArgs& a0, int waves) {
         a.early |= (waves_per_cu <= 12 ? 0 : waves_per_cu <= 16 ? 4 : 8) << 8;
     }
     const size_t smem = LdsLayout<SLOTS, KS>::BYTES;
-    if (smem > 64 * 1024) {   // long-K split kernels stage up to 32768 inputs: opt in to the CU's 160 KB once
-        static bool opted = false;
-        if (!opted) {
-            Q4_HIP(hipFuncSetAttribute((const void*)gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS, HALF>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            opted = true;
-        }
-    }
+    // long-K split kernels stage up to 32768 inputs: opt in to the CU's 160 KB (once per device)
+    { const int rc = lds_opt_in((const void*)gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS, HALF>, smem); if (rc) return rc; }
     Q4_LAUNCH((gemv_q4_kernel<MODE, SLOTS, COLS, NORM, ABL, KS, HALF>), grid, dim3(waves * 64), smem, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;

@@ -1,54 +1,15 @@
 // gemv_strip.h -- "strips": the fused gate/up GEMV (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275) on LDS-DMA rings. Ships
-// for wide matrices (ffn_strip_covers below); the profiling build runs every variant anywhere the shape is covered
-// (q4_set_gemv_early(11, 8..14); -1 = the wave-owned kernel always). NO loader wave: one 16-wave block per CU owns a contiguous range of columns;
-// every wave streams its OWN units -- unit u = wv + 16 i of the block's (column, matrix) pairs, 2 KiB each at K = 4096, 2.5 KiB at K = 5120 -- with
-// `buffer_load_dwordx4 ... nt lds` into a private ring of D 1 KiB pieces, waits for its oldest piece with vmcnt (a wave's loads return in order),
-// reads it back with ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD (the loader /
-// consumer engine of gemv_engine.hip had two), x staged once per CU by waves 0..7 (0..9) and held in 32 (48) registers by every wave. Same arithmetic
-// in the same order as gemv_q4_kernel<MODE_FFN>, bit for bit (tests/prof_cases.py).
-//   MODE 0 ("plain"): a wave sends its whole ring at entry and re-issues an entry when it has read it: D pieces in flight per wave.
-//   MODE 1 ("paced"): at most TWO pieces of a wave in flight whatever the depth of its ring (32 KiB per CU is what the CU's memory
-//          pipe takes without stalling the issue; more in flight measured slower): an issue is
-//          preceded by vmcnt(1). The waves that do not stage x fill their rings during the x chain, one piece per piece landed;
-//          the x chain synchronises through LDS counters (a wave stalled in vmcnt must not hold a hardware barrier up).
-//   MODE 2: MODE 1 with the dealing order rotated by eight waves: the waves that do not stage x take the longer share.
+// for wide matrices (ffn_strip_covers below). NO loader wave: one 16-wave block per CU owns a contiguous range of columns;
+// every wave streams its OWN units -- unit u = wave + 16 i of the block's (column, matrix) pairs, 2 KiB each at K = 4096, 2.5 KiB at K = 5120 -- with
+// `buffer_load_dwordx4 ... nt lds` into a private ring of two 1 KiB pieces (lds_dma.h), waits for its oldest piece with vmcnt (a wave's loads return
+// in order), reads it back with ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD, x staged
+// once per CU by waves 0..7 (0..9) and held in 32 (48) registers by every wave. Same arithmetic in the same order as gemv_q4_kernel<MODE_FFN>, bit for
+// bit (tests/prof_cases.py). Deeper rings, the paced issue and the stamped build live in exp/ffn_strip_variants.h (profiling library only).
 #pragma once
 #include "gemv_q4.h"
 #include "lds_dma.h"
 
 namespace q4 {
-
-// Flag words in LDS. A wave's LDS operations execute in program order, so "write data, then bump the flag" and "see the flag, then
-// read data" need no hardware fence inside a workgroup; the relaxed forms + compiler barriers keep hipcc from re-ordering them AND
-// from attaching its own waits: for an acquire / release at workgroup scope it emits s_waitcnt vmcnt(0) here (it cannot see the
-// asm LDS-DMA pieces, but it counts the x loads at the kernel's entry), which would drain the loader's stream at every flag.
-__device__ __forceinline__ unsigned lds_peek(unsigned* p) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_post(unsigned* p, unsigned v, unsigned lane) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_bump(unsigned* p, unsigned lane) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
-// Every wait is on a wave of the SAME block (all resident by construction: no scheduling order can wedge it), and still bounded
-// (~10 s): a wait that runs out -- a logic error, not a race -- raises the block's fail word, and the block then stores NaN, so the
-// failure is loud in every consumer of the result instead of a hung GPU or plausible garbage.
-constexpr unsigned ENG_SPIN_LIMIT = 1u << 27;
-__device__ __forceinline__ unsigned lds_wait_ge(unsigned* p, unsigned target, unsigned* fail) {
-    unsigned v = lds_peek(p);
-    for (unsigned n = 0; v < target; n++) {
-        if (n >= ENG_SPIN_LIMIT || ((n & 1023u) == 1023u && lds_peek(fail) != 0u)) { lds_post(fail, 1u, 0u); break; }
-        __builtin_amdgcn_s_sleep(1);
-        v = lds_peek(p);
-    }
-    return v;
-}
 
 constexpr int STRIP_WAVES = 16, STRIP_NCMAX = 56;
 // TS = k-slots of a column: 2 (K = 4096: two 1 KiB pieces) or 3 (K = 5120: two pieces and a half one, the shared half slot of gemv_q4.h)
@@ -64,24 +25,17 @@ struct StripLds {
     static constexpr unsigned SX = XS + TS * 4096u;                          // [TS][64] -(sum of the 32 x) * 2^-20
     static constexpr unsigned PART = SX + TS * 256u;                         // [TS * 256] rmsnorm chunk partials (zero past K / 8)
     static constexpr unsigned TOT = PART + TS * 1024u;                       // [NCMAX][2] column totals
-    static constexpr unsigned STAMP = TOT + 512u;                            // [64] wall-clock stamps (STAMPS builds)
-    static constexpr unsigned FLAGS = STAMP + 512u;                          // paced builds: sum-of-squares arrivals, staged arrivals, fail
+    static constexpr unsigned STAMP = TOT + 512u;                            // (laboratory variants, exp/ffn_strip_variants.h: [64] wall-clock stamps,
+    static constexpr unsigned FLAGS = STAMP + 512u;                          //  the paced forms' flag words; the product leaves both untouched)
     static constexpr unsigned BYTES = FLAGS + 64u;
 };
-enum { SF_SS = 0, SF_STAGED = 1, SF_FAIL = 2 };
 
-// stamps (tools/timeline_strip.py; kept in LDS and written out at the end: a global store would count in vmcnt): [0] wave 0 entry,
-// [1] its x landed, [2] sum of squares exchanged, [3] x staged, [4 + i] its unit i multiplied, [12] its totals written, [13] outputs
-// stored; [16 + w] wave w entry, [32 + w] wave w's first piece read, [48 + w] wave w's last unit multiplied
-#define SSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
-template <bool NORM, int D, int MODE, bool STAMPS, int TS = 2>
+template <bool NORM, int TS = 2>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
                                                                      const unsigned cbase, const unsigned crem, const GemvArgs a) {
     // the scalars the entry needs come first: built with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of
-    // through a scalar load from the kernel-argument segment (tools/timeline_strip.py: "x landed")
-    static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's pieces are compile-time constants");
-    static_assert(TS == 2 || (TS == 3 && MODE == 0 && D <= 4), "K = 5120: the plain form, 12 pieces per four units a multiple of the ring");
-    constexpr bool PACED = MODE >= 1;
+    // through a scalar load from the kernel-argument segment
+    constexpr int D = 2;                               // ring depth: two 1 KiB pieces per wave, 32 KiB in flight per CU (deeper rings measured level or slower)
     constexpr unsigned CB = TS == 2 ? 2048u : 2560u;   // bytes of a column
     constexpr unsigned G = TS == 2 ? 32u : 40u, ZW = TS == 2 ? 4u : 5u;   // its quantisation groups (one fp16 scale each), its words of zero nibbles
     constexpr int NSTAGE = TS == 2 ? 8 : 10;           // waves that stage x: one 8-half chunk per thread
@@ -92,19 +46,13 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
     const unsigned c0 = blockIdx.x * cbase + (blockIdx.x < crem ? blockIdx.x : crem);
     const int nc = (int)(cbase + (blockIdx.x < crem ? 1u : 0u));
     const int mat = wave & 1;
-    const int wv = MODE == 2 ? ((wave + 8) & 15) : wave;   // position in the dealing order
-    const int nu = (2 * nc - wv + 15) >> 4;            // this wave's units: u = wv + 16 i, column c0 + u / 2, matrix u % 2
+    const int nu = (2 * nc - wave + 15) >> 4;          // this wave's units: u = wave + 16 i, column c0 + u / 2, matrix u % 2
     const int npieces = TS * nu;
     const unsigned voff = lane * 16u;
     const bool stager = wave < NSTAGE;
     // K = 5120: a column's third piece is 512 bytes, 32 lanes. As in gemv_q4.h's shared half slot the lower half of the wave takes it
     // for the first column of a pair (even), the upper half for the second (odd): the same lanes add the same terms
     const bool upper = lane >= 32u;
-    unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + L::STAMP);
-    unsigned* flags = reinterpret_cast<unsigned*>(smem + L::FLAGS);
-    SSTAMP(16 + wave);
-    if (wave == 0) SSTAMP(0);
-    if (PACED && wave == 15 && lane < 16u) flags[lane] = 0u;
 
     // ---- what this wave will wait for first: x (its address arrives in SGPRs when the build preloads kernel arguments), side data, then its ring
     u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
@@ -119,30 +67,27 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
     constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);    // side pieces per matrix: scales (4 or 5 KiB) and zeros (1 or 2 KiB) of the block's columns
     if (wave < 2 * NSIDE) {
         const int m = wave >= NSIDE, p = wave - NSIDE * m;
-        if (p < (int)L::NS_S) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
-            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * (G * 2u) + p * 1024u);
+        if (p < (int)L::NS_S) {      // (descriptors based at the block's first column, bounded at the tensor's end: lds_dma.h)
+            const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[m].s, c0 * (G * 2u), (unsigned)(a.N * a.sh * 2));
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff + (unsigned)p * 1024u, rs, 0u);
         } else {
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
-            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff, rz, c0 * (ZW * 4u) + (p - (int)L::NS_S) * 1024u);
+            const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[m].z, c0 * (ZW * 4u), (unsigned)(a.N * a.pzh * 4));
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff + (unsigned)(p - (int)L::NS_S) * 1024u, rz, 0u);
         }
     }
-    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order); flags are zero
+    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
     const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
-    const unsigned soff0 = (c0 + ((unsigned)wv >> 1)) * CB;               // piece k = TS i + ks: soff0 + i * 8 columns + ks * 1024
-    const bool odd = ((c0 + ((unsigned)wv >> 1)) & 1u) != 0u;             // (a wave's columns are 8 apart: one parity)
+    const unsigned soff0 = (c0 + ((unsigned)wave >> 1)) * CB;             // piece k = TS i + ks: soff0 + i * 8 columns + ks * 1024
+    const bool odd = ((c0 + ((unsigned)wave >> 1)) & 1u) != 0u;           // (a wave's columns are 8 apart: one parity)
     const unsigned voff_half = (lane & 31u) * 16u;
     auto issue2 = [&](int i, int ks) {                 // piece ks of unit i (ks a constant at every call site)
         const unsigned dst = ring + (unsigned)((TS * i + ks) & (D - 1)) * 1024u, so = soff0 + (unsigned)i * (8u * CB) + (unsigned)ks * 1024u;
         if (TS == 3 && ks == 2) { if (upper == odd) dma_piece(dst, voff_half, rw, so); }   // 32 lanes: the LDS address follows the LANE, not the offset
         else dma_piece(dst, voff, rw, so);
     };
-    auto issue = [&](int k) { static_assert(TS == 2 || !PACED, "linear piece numbers: two pieces per unit"); issue2(k >> 1, k & 1); };
-    constexpr int D0 = PACED ? 2 : D;                  // pieces a wave sends at entry
-    int I = npieces < D0 ? npieces : D0;               // pieces issued so far
 #pragma unroll
-    for (int k = 0; k < D0; k++)
+    for (int k = 0; k < D; k++)                        // the wave sends its whole ring at entry
         if (k < npieces) issue2(k / TS, k % TS);
 
     // ---- x chain (gemv_q4_body's staging, one 8-half chunk per thread of waves 0..7)
@@ -150,16 +95,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
     float* sx = reinterpret_cast<float*>(smem + L::SX);
     float* part = reinterpret_cast<float*>(smem + L::PART);
     float* tot = reinterpret_cast<float*>(smem + L::TOT);
-    if (stager || !PACED) {
-        if (npieces >= D0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xraw), "+v"(wraw) : "n"(D0) : "memory");   // all but the weight pieces
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xraw), "+v"(wraw) : : "memory");                            // (a narrow matrix: fewer were issued)
-    }
-    if (wave == 0) SSTAMP(1);
+    if (npieces >= D) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xraw), "+v"(wraw) : "n"(D) : "memory");   // all but the weight pieces
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(xraw), "+v"(wraw) : : "memory");                          // (a narrow matrix: fewer were issued)
     if (NORM) {
         if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;      // (K = 5120: entries 640 .. 767 are the zero padding of the canonical sum)
-        if (!PACED) block_barrier_lds();
-        else if (stager) { lds_bump(&flags[SF_SS], lane); lds_wait_ge(&flags[SF_SS], 8u, &flags[SF_FAIL]); }
-        if (wave == 0) SSTAMP(2);
+        block_barrier_lds();
     }
     if (stager) {
         float ss = 1.f;
@@ -176,25 +116,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
         xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
         if (d == 0) sx[j] = cb * -9.5367431640625e-07f;     // -(sum x) * 2^-20
     }
-    if (!PACED) block_barrier_lds();                   // x staged; side data landed (its issuers passed the vmcnt wait above)
-    else {
-        if (stager) lds_bump(&flags[SF_STAGED], lane);                      // a wave's LDS operations execute in order: its writes are in front
-        else {
-            // the other eight waves fill their rings meanwhile, one piece for every piece that lands (never more than two in flight);
-            // waves 8 and 9 carry side pieces: theirs are older than their ring, so "at most one outstanding" covers them
-            bool told = wave >= 10;
-            while (I < npieces && I < D) {
-                wait_vmcnt<1>();
-                if (!told) { lds_bump(&flags[SF_STAGED], lane); told = true; }
-                issue(I);
-                I++;
-                if (lds_peek(&flags[SF_STAGED]) >= 10u) break;
-            }
-            if (!told) { wait_vmcnt<1>(); lds_bump(&flags[SF_STAGED], lane); }
-        }
-        lds_wait_ge(&flags[SF_STAGED], 10u, &flags[SF_FAIL]);
-    }
-    if (wave == 0) SSTAMP(3);
+    block_barrier_lds();                               // x staged; side data landed (its issuers passed the vmcnt wait above)
     u32x4 X[TS][4];
     float corr[TS];
 #pragma unroll
@@ -205,8 +127,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
         corr[ks] = sx[ks * 64 + lu];
     }
     const unsigned char* wbase = smem + ring + lane * 16u;
-    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wv >> 1) * G + (lane >> 2)) * 2u;   // + i * 8 columns * 64 (80) B
-    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wv >> 1) * ZW + (lane >> 5)) * 4u;    // + i * 8 columns * 16 (20) B
+    const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wave >> 1) * G + (lane >> 2)) * 2u;   // + i * 8 columns * 64 (80) B
+    const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wave >> 1) * ZW + (lane >> 5)) * 4u;    // + i * 8 columns * 16 (20) B
     const unsigned zsh = ((lane >> 2) & 7u) * 4u;
 
     for (int g4 = 0; g4 * 4 < nu; g4++) {
@@ -222,21 +144,15 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     constexpr int DM1 = D - 1;
                     const int e = (TS * r + ks) & DM1;                      // j % D (4 TS g4 is a multiple of D)
                     const bool hs = TS == 3 && ks == 2;                     // the half slot
-                    if (!PACED) {
-                        // piece j has landed. D = 2: exact -- the stream's last piece but one does not wait for the last (13B 580.3 -> 583.2, Mistral geometry
-                        // 913.2 -> 914.4 tokens/s, tools/ab.py); deeper rings (profiling) drain at their last D pieces
-                        if (D == 2 ? j + 1 < npieces : j + D < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();
-                    } else {
-                        if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();     // pieces < I - 1 have landed, and I >= j + 2: piece j has
-                        if (I < npieces && I - j < D) { issue(I); I++; }    // at most one was in flight: now two; the entry's last reader was piece I - D < j
-                    }
-                    if (j == 0) SSTAMP(32 + wave);
+                    // piece j has landed -- exact: the stream's last piece but one does not wait for the last (13B 580.3 -> 583.2, Mistral geometry
+                    // 913.2 -> 914.4 tokens/s, tools/ab.py)
+                    if (j + 1 < npieces) wait_vmcnt<DM1>(); else wait_vmcnt<0>();
                     const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
                     // scale and zero word of this lane's group: 16 ks + lane / 4, in the half slot 32 + (lane % 32) / 4
                     const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (8u * G * 2u) + (hs ? 64 - (int)(upper ? 16u : 0u) : ks * 32));
                     const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (8u * ZW * 4u) + (hs ? 16 - (int)(upper ? 4u : 0u) : ks * 8));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
-                    if (!PACED && j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
+                    if (j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
                     float acc_e = 0.f, acc_o = 0.f;
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
@@ -263,29 +179,21 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_kernel(const u32x4
                     if (TS == 3) asm volatile("" : "+v"(c));
                 }
                 cs[r] = c;
-                if (STAMPS) { asm volatile("" : "+v"(c)); if (wave == 0 && i < 8) SSTAMP(4 + i); if (i == nu - 1) SSTAMP(48 + wave); }
             }
         }
         const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit g4 * 4 + r
         const int row = lane >> 4;
-        if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wv + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
+        if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wave + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
     }
-    if (wave == 0) SSTAMP(12);
     block_barrier_lds();
     if ((int)tid < nc) {
         const float g = tot[2 * tid], u = tot[2 * tid + 1];
         float val = g;
         val *= 1.0f / (1.0f + expf(-val));              // gpu_kernels.h:271
         val *= u;                                       // :272
-        a.out[0][c0 + tid] = (PACED && lds_peek(&flags[SF_FAIL]) != 0u) ? (uint16_t)0x7E00u : f2h(val);   // (NaN: a wait ran out)
-    }
-    if (STAMPS) {
-        if (wave == 0) SSTAMP(13);
-        block_barrier_lds();
-        if (a.dbg && tid < 64u) a.dbg[(size_t)blockIdx.x * 64 + tid] = st[tid];
+        a.out[0][c0 + tid] = f2h(val);
     }
 }
-#undef SSTAMP
 
 // K = 5120 with PAIR units: a wave's unit is a pair of adjacent columns (c even, c + 1) of one matrix = FIVE full 1 KiB pieces -- c k-slot 0, c k-slot 1,
 // c + 1 k-slot 0, c + 1 k-slot 1 and ONE piece for both columns' last 32 uint4 (lanes 0-31 fetch column c's, lanes 32-63 column c + 1's: the load and the
@@ -325,12 +233,12 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const 
     constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);
     if (wave < 2 * NSIDE) {
         const int m = wave >= NSIDE, p = wave - NSIDE * m;
-        if (p < (int)L::NS_S) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].s, 0, a.N * a.sh * 2, 0x00020000);
-            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff, rs, c0 * (G * 2u) + p * 1024u);
+        if (p < (int)L::NS_S) {      // (descriptors based at the block's first column, bounded at the tensor's end: lds_dma.h)
+            const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[m].s, c0 * (G * 2u), (unsigned)(a.N * a.sh * 2));
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + p * 1024u, voff + (unsigned)p * 1024u, rs, 0u);
         } else {
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[m].z, 0, a.N * a.pzh * 4, 0x00020000);
-            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff, rz, c0 * (ZW * 4u) + (p - (int)L::NS_S) * 1024u);
+            const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[m].z, c0 * (ZW * 4u), (unsigned)(a.N * a.pzh * 4));
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (p - (int)L::NS_S) * 1024u, voff + (unsigned)(p - (int)L::NS_S) * 1024u, rz, 0u);
         }
     }
     block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece
@@ -449,21 +357,16 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const 
 }
 
 // Shapes: K = 4096 (two 1 KiB pieces per column), 16 .. 56 columns per CU, on a stream that may use every CU (the blocks do not wait for
-// each other: on a CU-masked stream the form would be correct, only slow). g_engine: 0 = the product's choice -- strips from
-// STRIP_MIN_COLS columns per CU on, where the wave-owned kernel's grid needs a seventh row of blocks per CU and strips measure
-// faster (tools/sweep_strips.py, per launch in a graph: 12800 columns 11.83 -> 10.56 us, 13312 11.89 -> 10.96, the Mistral / Llama-3
-// hidden size 14336 12.4 -> 11.45, 885 -> 902 tokens/s on the Mistral-7B geometry; up to 48 columns per CU -- Llama-2-7B's 11008 is 43 --
-// the two were level at first: the threshold was 49 until the strips' kernel arguments were preloaded (csrc/Makefile GEMVFLAGS) and their last
-// piece but one stopped draining. With both, per launch in a graph, wave-owned | strips: 16 columns per CU 4.92 | 5.39 us, 20: 5.88 | 5.92, 24: 6.25 |
-// 6.46, 28: 7.12 | 6.98, 32: 7.78 | 7.75, 36: 8.57 | 8.23, 40: 9.15 | 9.01, 43 (Llama-2-7B): 10.12 | 9.69, 46: 10.08 | 9.72; Llama-2-7B -n 256
-// 982.7 -> 990.8, -n 2048 872.6 -> 879.5 tokens/s (tools/ab.py against a build with the threshold at 43)) --; the profiling build also takes
-// -1 = never, 8 .. 14 = this variant wherever the shape is covered.
+// each other: on a CU-masked stream the form would be correct, only slow). Strips run from STRIP_MIN_COLS columns per CU on, where they measure
+// faster than the wave-owned kernel (tools/sweep_strips.py, per launch in a graph, wave-owned | strips: 16 columns per CU 4.92 | 5.39 us, 20: 5.88 | 5.92,
+// 24: 6.25 | 6.46, 28: 7.12 | 6.98, 32: 7.78 | 7.75, 36: 8.57 | 8.23, 40: 9.15 | 9.01, 43 (Llama-2-7B): 10.12 | 9.69, 46: 10.08 | 9.72; the Mistral /
+// Llama-3 hidden size 14336: 12.4 -> 11.45 us, 885 -> 902 tokens/s on the Mistral-7B geometry; Llama-2-7B -n 256 982.7 -> 990.8 tokens/s against a build
+// with the threshold at 49). g_gemv_form (q4_internal.h) is GEMV_PRODUCT in the shipped library; the profiling library's knob 11 sets the others.
 #ifdef Q4_STRIP_MIN_COLS
 constexpr int STRIP_MIN_COLS = Q4_STRIP_MIN_COLS;   // (make exp EXPFLAGS_GEMV=-DQ4_STRIP_MIN_COLS=49: the wave-owned kernel for Llama-2-7B's gate/up, for the A/B)
 #else
 constexpr int STRIP_MIN_COLS = 36;
 #endif
-extern int g_engine;
 static inline bool strip_k5120(const GemvArgs& a) { return a.K == 5120 && a.pw4 == 160 && a.sh == 40 && a.pzh == 5; }
 static bool ffn_strip_shape(const GemvArgs& a) {
     const int nb = cu_count();
@@ -472,25 +375,15 @@ static bool ffn_strip_shape(const GemvArgs& a) {
     return k && a.N / nb >= 16 && divUp(a.N, nb) <= STRIP_NCMAX && stream_cu_count() == nb;
 }
 static bool ffn_strip_covers(const GemvArgs& a) {
-    if (g_engine == 0 || g_engine == 15 || g_engine == 19) return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);   // (15: profiling, the product's gate/up choice without the down-projection strips)
-#ifdef Q4_PROFILING
-    return g_engine >= 8 && g_engine <= 14 && g_engine != 11 && g_ablate == 0 && ffn_strip_shape(a);
-#else
-    return false;
-#endif
+    if (g_gemv_form != GEMV_PRODUCT && g_gemv_form != GEMV_PRODUCT_NO_DOWN_STRIPS && g_gemv_form != GEMV_K5120_COLUMN_UNITS) return false;   // (GEMV_WAVE_OWNED; the laboratory forms answer through g_lab first)
+    return a.N / cu_count() >= STRIP_MIN_COLS && g_ablate == 0 && ffn_strip_shape(a);
 }
-template <bool NORM, int D, int MODE, bool STAMPS, int TS = 2>
+template <bool NORM, int TS>
 static int launch_strip(const GemvArgs& a) {
-    constexpr size_t smem = StripLds<D, TS>::BYTES;
-    if (smem > 64 * 1024) {    // (the product's D = 2 form needs 54 KiB: no opt-in, nothing that a graph capture could not record)
-        static bool opted = false;
-        if (!opted) {
-            Q4_HIP(hipFuncSetAttribute((const void*)ffn_strip_kernel<NORM, D, MODE, STAMPS, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            opted = true;
-        }
-    }
+    constexpr size_t smem = StripLds<2, TS>::BYTES;
+    static_assert(smem <= 64 * 1024, "54 KiB: no opt-in, nothing that a graph capture could not record");
     const unsigned nb = (unsigned)cu_count();
-    Q4_LAUNCH((ffn_strip_kernel<NORM, D, MODE, STAMPS, TS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
+    Q4_LAUNCH((ffn_strip_kernel<NORM, TS>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
               (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), (unsigned)a.N / nb, (unsigned)a.N % nb, a);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
@@ -510,34 +403,10 @@ static int launch_strip_pair(const GemvArgs& a) {
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
-#ifdef Q4_PROFILING
-template <bool NORM, bool STAMPS>
-static int launch_strip_setting(const GemvArgs& a) {
-    switch (g_engine) {
-        case 9: return launch_strip<NORM, 4, 0, STAMPS>(a);
-        case 10: return launch_strip<NORM, 8, 0, STAMPS>(a);
-        case 12: return launch_strip<NORM, 4, 1, STAMPS>(a);
-        case 13: return launch_strip<NORM, 8, 1, STAMPS>(a);
-        case 14: return launch_strip<NORM, 8, 2, STAMPS>(a);
-        default: return launch_strip<NORM, 2, 0, STAMPS>(a);   // 0 (the product's form), 8
-    }
-}
 static int launch_ffn_strip(const GemvArgs& a) {
-    const bool norm = a.rms_w != nullptr;
-    if (g_engine != 19 && g_engine != 9 && strip_pairs(a)) return launch_strip_pair(a);   // (19: the column-unit form of K = 5120, for the A/B)
-    if (strip_k5120(a)) {
-        if (g_engine == 9) return norm ? launch_strip<true, 4, 0, false, 3>(a) : launch_strip<false, 4, 0, false, 3>(a);
-        return norm ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
-    }
-    if (a.dbg) return norm ? launch_strip_setting<true, true>(a) : launch_strip_setting<false, true>(a);
-    return norm ? launch_strip_setting<true, false>(a) : launch_strip_setting<false, false>(a);
+    if (g_gemv_form != GEMV_K5120_COLUMN_UNITS && strip_pairs(a)) return launch_strip_pair(a);   // (the column-unit form of K = 5120 otherwise: uneven splits, and the A/B)
+    if (strip_k5120(a)) return a.rms_w ? launch_strip<true, 3>(a) : launch_strip<false, 3>(a);
+    return a.rms_w ? launch_strip<true, 2>(a) : launch_strip<false, 2>(a);
 }
-#else
-static int launch_ffn_strip(const GemvArgs& a) {
-    if (strip_pairs(a)) return launch_strip_pair(a);
-    if (strip_k5120(a)) return a.rms_w ? launch_strip<true, 2, 0, false, 3>(a) : launch_strip<false, 2, 0, false, 3>(a);
-    return a.rms_w ? launch_strip<true, 2, 0, false>(a) : launch_strip<false, 2, 0, false>(a);
-}
-#endif
 
 }  // namespace q4

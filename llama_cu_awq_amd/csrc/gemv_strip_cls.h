@@ -8,11 +8,8 @@
 // more than that launch, 256 blocks do not. Measured (7B, one call): the launch with the norm inside 42.7 / 42.1 / 40.7 us at ring
 // depth 2 / 4 / 8 against 40.2 + 4.7 us for gemv_f16_kernel behind rmsnorm_kernel -- a 262 MB stream sustains 6.2-6.5 TB/s on this chip whatever is in
 // flight --, 969.3 -> 973.0 / 971.8 tokens/s at depth 4 / 8: depth 4 ships.
-// AM: the greedy sampler (argmax_kernel, gpu_kernels.h:448-493; llama2_q4.cu:384 -> sampler.h:47-49) as this launch's epilogue. Every wave keeps the
-// best of its own rows (the fp16-rounded logit it stores, first maximum = lowest row), a block leaves ONE candidate {value, row} (written through,
-// drained) and one returning arrival; the block that arrives last reads the 256 candidates, decides with argmax_kernel's rule (value, then the lower
-// index), copies the winner's embedding row for the next step where asked, writes the token ring and advances both position words. One launch and one
-// boundary fewer per greedy token; the logits are stored as before.
+// An epilogue policy sees every logit a wave stores (exp/cls_argmax.h: the greedy sampler as this launch's epilogue, measured level and not shipped;
+// the product's policy is empty).
 #pragma once
 #include "gemv_strip.h"
 
@@ -26,26 +23,13 @@ struct StripClsLds {
     static constexpr unsigned BYTES = PART + NS * 256u;
 };
 
-// the greedy sampler's tail inside the classifier launch: argmax_kernel's arguments + the launch's own hand-off words
-struct ClsArgmax {
-    unsigned* counter;                 // arrival counter, zero between launches (the last arriver re-arms it)
-    unsigned long long* cand;          // one {value bits, row} word per block
-    int* result;                       // SharedData::tokens
-    volatile int* pPos;                // SharedData::pos (pinned host word)
-    int* pPosGpu;                      // RunState::pos
-    int write_token;
-    q4_half* x_next;                   // the next step's residual stream (the winner's embedding row goes there) or null
-    const q4_half* table;
-    int dim;
+struct ClsNoEpilogue {     // the product: nothing rides on the classifier launch
+    __device__ __forceinline__ void entry(unsigned) {}
+    __device__ __forceinline__ void row(q4_half, int) {}
 };
-__device__ __forceinline__ void argmax_merge(float& v, int& ix, float ov, int op) {      // argmax_kernel's rule: value, then the lower index
-    if (ov > v || (ov == v && op < ix)) { v = ov; ix = op; }
-}
-
-template <int NS, bool NORM, int D, bool AM = false>
-__global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w, const unsigned wbytes,
-                                                                    const unsigned rbase, const unsigned rrem, q4_half* __restrict__ out, const int n, const unsigned row_bytes,
-                                                                    const ClsArgmax am) {
+template <int NS, bool NORM, int D, typename EPI>
+__device__ __forceinline__ void cls_strip_body(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w, const unsigned wbytes,
+                                               const unsigned rbase, const unsigned rrem, q4_half* __restrict__ out, const int n, const unsigned row_bytes, EPI& epi) {
     using L = StripClsLds<NS, D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -97,10 +81,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4
     for (int s = 0; s < NS; s++) X[s] = xn[s * 64 + lane];
     const unsigned char* wbase = smem + ring + lane * 16u;
 
-    float best = -INFINITY;          // (wave-uniform: wave_sum's result is)
-    int best_row = 0x7fffffff;
-    int token_pos = 0;
-    if (AM && tid == 0) token_pos = *am.pPosGpu;       // long landed when the epilogue wants it (the previous launch of the stream wrote it)
+    epi.entry(tid);
     for (int i = 0; i < nu; i++) {
         float sum = 0.f;
 #pragma unroll
@@ -119,114 +100,39 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4
         t *= 1.0f;                                                             // alpha, gpu_kernels.h:135
         const q4_half th = f2h(t);
         if (lane == 0) out[r0 + (unsigned)wave + 16u * (unsigned)i] = th;
-        if (AM) {                                                              // ascending rows, strict: the first maximum stays (argmax_kernel :160-173)
-            const float v = h2f(th);
-            if (v > best) { best = v; best_row = (int)(r0 + (unsigned)wave + 16u * (unsigned)i); }
-        }
+        epi.row(th, (int)(r0 + (unsigned)wave + 16u * (unsigned)i));           // (wave-uniform: wave_sum's result is)
     }
-    if (!AM) return;
-    // ---- argmax_kernel as the epilogue of the launch
-    float* sval = reinterpret_cast<float*>(smem + L::PART);                    // (the rmsnorm partials are long read)
-    int* sidx = reinterpret_cast<int*>(smem + L::PART + 64);
-    int* sflag = reinterpret_cast<int*>(smem + L::PART + 128);
-    if (lane == 0) { sval[wave] = best; sidx[wave] = best_row; }
-    __syncthreads();
-    if (tid == 0) {
-        float v = sval[0];
-        int ix = sidx[0];
-        for (int w = 1; w < STRIP_WAVES; w++) argmax_merge(v, ix, sval[w], sidx[w]);
-        const unsigned long long c = (unsigned long long)(unsigned)as_i(v) | ((unsigned long long)(unsigned)ix << 32);
-        unsigned long long* dst = am.cand + blockIdx.x;
-        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(c) : "memory");   // written through, acknowledged
-        const unsigned old = __hip_atomic_fetch_add(am.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old == gridDim.x - 1u;
-        if (last) __hip_atomic_store(am.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                      // re-armed for the next launch
-        *sflag = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (*sflag == 0) return;
-    // the block that arrived last: every candidate is in memory
-    float v = -INFINITY;
-    int ix = 0x7fffffff;
-    for (unsigned b = tid; b < gridDim.x; b += STRIP_WAVES * 64) {
-        const unsigned long long c = __hip_atomic_load(am.cand + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        argmax_merge(v, ix, as_f((int)(unsigned)c), (int)(unsigned)(c >> 32));
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off);
-        const int op = __shfl_xor(ix, off);
-        argmax_merge(v, ix, ov, op);
-    }
-    __syncthreads();                                                           // (thread 0 has read the block's own totals)
-    if (lane == 0) { sval[wave] = v; sidx[wave] = ix; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < STRIP_WAVES; w++) argmax_merge(v, ix, sval[w], sidx[w]);
-        if (ix == 0x7fffffff) ix = 0;                                          // all NaN / -inf
-        *sflag = ix;
-    }
-    if (am.x_next != nullptr) {                                                // (uniform: a kernel argument) every other block is done with x
-        __syncthreads();
-        const int token = *sflag;
-        // the upper waves copy the row while wave 0 publishes the token: two memory round trips side by side instead of in series
-        for (int u = (int)tid - 512; u >= 0 && u < (am.dim >> 3); u += 512)
-            reinterpret_cast<u32x4*>(am.x_next)[u] = reinterpret_cast<const u32x4*>(am.table + (size_t)token * am.dim)[u];
-    }
-    if (tid == 0) {
-        token_pos++;
-        if (am.write_token) am.result[token_pos] = ix;                         // gpu_kernels.h:486-487
-        __threadfence_system();                                                // the host may be spinning on *pPos (q4_wait_pos)
-        *am.pPos = token_pos;                                                  // :490 (unblocks the CPU)
-        *am.pPosGpu = token_pos;                                               // :491
-    }
+}
+template <int NS, bool NORM, int D>
+__global__ void __launch_bounds__(STRIP_WAVES * 64) cls_strip_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w, const unsigned wbytes,
+                                                                    const unsigned rbase, const unsigned rrem, q4_half* __restrict__ out, const int n, const unsigned row_bytes) {
+    ClsNoEpilogue none;
+    cls_strip_body<NS, NORM, D>(arg_x, arg_rms, arg_w, wbytes, rbase, rrem, out, n, row_bytes, none);
 }
 
 // n = 4096 or 5120 inputs (8 or 10 pieces per row), contiguous rows, one right-hand side, alpha = 1, at least 64 rows per CU, a stream that may use every CU
 static bool cls_strip_covers(int n, int d, int batch, int w_row_stride, float alpha) {
-    if (g_engine != 0 && g_engine != 8 && g_engine != 19) return false;
+    if (g_gemv_form != GEMV_PRODUCT && g_gemv_form != GEMV_STRIPS_EVERYWHERE && g_gemv_form != GEMV_K5120_COLUMN_UNITS) return false;
     const int nb = cu_count();
     return (n == 4096 || n == 5120) && batch == 1 && w_row_stride == n && alpha == 1.0f && d / nb >= 64 && (long long)d * n * 2 < (1ll << 31) &&
            g_ablate == 0 && stream_cu_count() == nb;
 }
 constexpr int CLS_D = 4;   // ring depth: 74-76 KiB of LDS, opted in by cls_strip_prepare()
-// the LDS opt-in is not a stream operation: q4_set_device and build_transformer make it (q4_runtime.hip), outside any capture
-int cls_strip_prepare() {
-    static bool opted = false;
-    if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, true, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, false, CLS_D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
-#ifdef Q4_PROFILING     // the sampler-epilogue form exists in the profiling build only (knob 12)
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<8, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<8, CLS_D>::BYTES));
-        Q4_HIP(hipFuncSetAttribute((const void*)cls_strip_kernel<10, true, CLS_D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripClsLds<10, CLS_D>::BYTES));
-#endif
-        opted = true;
-    }
-    return Q4_OK;
-}
-template <int NS, bool NORM, int D, bool AM>
-static int launch_cls_strip_d(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d, const ClsArgmax& am) {
+// (cls_strip_prepare, q4_kernels.hip: the LDS opt-in is not a stream operation -- build_transformer makes it, outside any capture)
+template <int NS, bool NORM, int D>
+static int launch_cls_strip_d(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d) {
     { const int rc = cls_strip_prepare(); if (rc) return rc; }
     const unsigned nb = (unsigned)cu_count();
     constexpr size_t smem = StripClsLds<NS, D>::BYTES;
-    Q4_LAUNCH((cls_strip_kernel<NS, NORM, D, AM>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(rms_w),
-              (const void*)w, (unsigned)((size_t)d * n * 2), (unsigned)d / nb, (unsigned)d % nb, out, n, (unsigned)n * 2u, am);
+    Q4_LAUNCH((cls_strip_kernel<NS, NORM, D>), dim3(nb), dim3(STRIP_WAVES * 64), smem, reinterpret_cast<const u32x4*>(x), reinterpret_cast<const u32x4*>(rms_w),
+              (const void*)w, (unsigned)((size_t)d * n * 2), (unsigned)d / nb, (unsigned)d % nb, out, n, (unsigned)n * 2u);
     Q4_LAUNCH_CHECK();
     return Q4_OK;
 }
-// rms_w != nullptr: out = W . rmsnorm(x, rms_w) (x itself is left as it is); else out = W . x. am != nullptr (with rms_w): the greedy sampler as the
-// launch's epilogue
-static int launch_cls_strip(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d, const ClsArgmax* am) {
-    const ClsArgmax none = {};
-#ifdef Q4_PROFILING
-    if (am && rms_w) return n == 4096 ? launch_cls_strip_d<8, true, CLS_D, true>(out, x, rms_w, w, n, d, *am) : launch_cls_strip_d<10, true, CLS_D, true>(out, x, rms_w, w, n, d, *am);
-#else
-    (void)am;
-#endif
-    if (n == 4096) return rms_w ? launch_cls_strip_d<8, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<8, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
-    return rms_w ? launch_cls_strip_d<10, true, CLS_D, false>(out, x, rms_w, w, n, d, none) : launch_cls_strip_d<10, false, CLS_D, false>(out, x, nullptr, w, n, d, none);
+// rms_w != nullptr: out = W . rmsnorm(x, rms_w) (x itself is left as it is); else out = W . x
+static int launch_cls_strip(q4_half* out, const q4_half* x, const q4_half* rms_w, const q4_half* w, int n, int d) {
+    if (n == 4096) return rms_w ? launch_cls_strip_d<8, true, CLS_D>(out, x, rms_w, w, n, d) : launch_cls_strip_d<8, false, CLS_D>(out, x, nullptr, w, n, d);
+    return rms_w ? launch_cls_strip_d<10, true, CLS_D>(out, x, rms_w, w, n, d) : launch_cls_strip_d<10, false, CLS_D>(out, x, nullptr, w, n, d);
 }
 
 }  // namespace q4

@@ -60,11 +60,11 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
     }
     if (wave < 8) {                                    // scales (6 KiB) and zeros (2 KiB) of the block's columns
         if (wave < 6) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[0].s, 0, a.N * a.sh * 2, 0x00020000);
-            dma_piece_default(L::SIDE_S + (unsigned)wave * 1024u, voff, rs, c0 * (unsigned)a.sh * 2u + (unsigned)wave * 1024u);
+            const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[0].s, c0 * (unsigned)a.sh * 2u, (unsigned)(a.N * a.sh * 2));   // (bounded at the tensor's end: lds_dma.h)
+            dma_piece_default(L::SIDE_S + (unsigned)wave * 1024u, voff + (unsigned)wave * 1024u, rs, 0u);
         } else {
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.m[0].z, 0, a.N * a.pzh * 4, 0x00020000);
-            dma_piece_default(L::SIDE_Z + (unsigned)(wave - 6) * 1024u, voff, rz, c0 * (unsigned)a.pzh * 4u + (unsigned)(wave - 6) * 1024u);
+            const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[0].z, c0 * (unsigned)a.pzh * 4u, (unsigned)(a.N * a.pzh * 4));
+            dma_piece_default(L::SIDE_Z + (unsigned)(wave - 6) * 1024u, voff + (unsigned)(wave - 6) * 1024u, rz, 0u);
         }
     }
     block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece
@@ -189,18 +189,18 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
 // the shapes: the K-split kernel (two k-parts, ku uint4 each) with up to four slots per part and at most seven 64-unit rows of x (K <= 14336), no KV
 // addressing, on a stream that may use every CU; 8 .. 24 columns per block. Llama-2-13B: K = 13824, four slots, the last shared (24 units): 9.83 ->
 // 8.64 us per launch, the product's choice. Llama-2-7B: K = 11008, three slots, the last an ordinary one of 44 units: bit-identical as well, and
-// SLOWER than the K-split kernel's 512 blocks = exactly two per CU (962 -> 936 tokens/s): only under the profiling build's knob 11 = 8
+// SLOWER than the K-split kernel's 512 blocks = exactly two per CU (962 -> 936 tokens/s): only under the profiling build's GEMV_STRIPS_EVERYWHERE
 // (which forces strips wherever the shape is covered).
 static bool down_strip_covers(const GemvArgs& a, bool shared) {
     const int nb = cu_count();
-    if (g_engine == 0 || g_engine == 19) {
+    if (g_gemv_form == GEMV_PRODUCT || g_gemv_form == GEMV_K5120_COLUMN_UNITS) {
         // the product's choice: the shared-slot form (four slots per k-part, K = 13824 / 14336). It was taken only where the K-split kernel's grid (8 columns
         // per block) leaves the CUs uneven -- 13B: 640 blocks = 2.5 per CU, the launch pays for three; strips 536 -> 546 tokens/s -- because on an even grid
         // the K-split kernel was faster (Mistral geometry, K = 14336, 512 blocks: strips 899 -> 890 tokens/s). With the strips' kernel arguments preloaded
         // (csrc/Makefile GEMVFLAGS), their arithmetic pinned per piece and the exact tail wait they win there too: 7.63 -> 7.47 us per launch, 908.3 -> 914.1
         // tokens/s. The three-slot form (Llama-2-7B, K = 11008) still loses (6.02 vs 6.30 us) and stays a profiling knob.
         if (!shared) return false;
-    } else if (g_engine != 8) return false;
+    } else if (g_gemv_form != GEMV_STRIPS_EVERYWHERE) return false;
     const int sh = divUp(a.ku, 64);
     const bool shape = shared ? (sh == 4 && a.ku - (sh - 1) * 64 <= 32) : (sh == 3 && a.ku - (sh - 1) * 64 > 32);
     return a.nslots >= 5 && shape && a.ku * 2 >= a.pw4 && divUp(a.pw4, 64) <= SD_ROWS && a.loff == -1 && a.rms_w == nullptr &&
@@ -208,13 +208,8 @@ static bool down_strip_covers(const GemvArgs& a, bool shared) {
 }
 // 70 KiB of LDS: the opt-in is not a stream operation -- build_transformer makes it for the model (q4_runtime.hip), a stand-alone call at its first launch
 int down_strip_prepare() {
-    static bool opted = false;
-    if (!opted) {
-        Q4_HIP(hipFuncSetAttribute((const void*)down_strip_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripDownLds::BYTES));
-        Q4_HIP(hipFuncSetAttribute((const void*)down_strip_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripDownLds::BYTES));
-        opted = true;
-    }
-    return Q4_OK;
+    const int rc = lds_opt_in((const void*)down_strip_kernel<4, true>, StripDownLds::BYTES);      // (once per device)
+    return rc ? rc : lds_opt_in((const void*)down_strip_kernel<3, false>, StripDownLds::BYTES);
 }
 template <int SH, bool SHARED>
 static int launch_down_strip(const GemvArgs& a) {

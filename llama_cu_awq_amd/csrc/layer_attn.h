@@ -45,21 +45,38 @@ struct AttOprojArgs {
 // ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3 / 4: one block per (head, 128 / 256 / 64
 // positions), merged by each head's first chunk block; 5 / 6: 0 / 1 with head_size / 32 blocks per head, each taking one 64-byte
 // slice of the V rows (attention.h, VS; the default below bin 512). LPR = lanes per cache row of a head (head_size / 8).
-// 7 / 8 / 9: the split-context forms 2 / 3 / 4 with their K / V rows on LDS-DMA rings (attention.h, RING; bit-identical records).
+// 7 / 8 / 9 (laboratory, profiling library only): the split-context forms 2 / 3 / 4 with their K / V rows on LDS-DMA rings (exp/attention_ring.h; same bits,
+// measured level).
 #ifndef Q4_ATT_RING
-#define Q4_ATT_RING 4                // 1 KiB pieces per wave of the ring forms (make exp EXPFLAGS_ATTN=-DQ4_ATT_RING=8 for the A/B)
+#define Q4_ATT_RING 4                // 1 KiB pieces per wave of the ring forms (tools/build_ring_variants.sh builds other depths for the A/B)
 #endif
 // block LDS of the launch: the default 64 KiB without an opt-in; ring depths of 8 pieces and more (A/B builds) opt in where they are first asked for
 constexpr size_t AO_LDS_MAX = Q4_ATT_RING > 7 ? 160 * 1024 : 64 * 1024;
 constexpr bool att_is_split(int att) { return (att >= 2 && att <= 4) || (att >= 7 && att <= 9); }
 constexpr int att_ring(int att) { return att >= 7 && att <= 9 ? Q4_ATT_RING : 0; }
+template <int ATT> struct AttLoad { using type = KvInRegisters; };
+#ifdef Q4_PROFILING
+}  // namespace q4
+#include "exp/attention_ring.h"
+namespace q4 {
+template <> struct AttLoad<7> { using type = KvOnRings<Q4_ATT_RING>; };
+template <> struct AttLoad<8> { using type = KvOnRings<Q4_ATT_RING>; };
+template <> struct AttLoad<9> { using type = KvOnRings<Q4_ATT_RING>; };
+#define Q4_AO_LAB_CASES(LPR)                                                                                                         \
+    case 7: return go(attention_oproj_kernel<2, false, 7, LPR>); case 8: return go(attention_oproj_kernel<2, false, 8, LPR>);        \
+    case 9: return go(attention_oproj_kernel<2, false, 9, LPR>); case 23: return go(attention_oproj_kernel<3, true, 7, LPR>);        \
+    case 24: return go(attention_oproj_kernel<3, true, 8, LPR>); case 25: return go(attention_oproj_kernel<3, true, 9, LPR>);        \
+    case 39: return go(attention_oproj_kernel<4, false, 7, LPR>); case 40: return go(attention_oproj_kernel<4, false, 8, LPR>);      \
+    case 41: return go(attention_oproj_kernel<4, false, 9, LPR>);
+#else
+#define Q4_AO_LAB_CASES(LPR)
+#endif
 template <int LPR, int ATT>
 struct AttShape {
     static constexpr int CHUNK = ATT == 4 || ATT == 9 ? 64 : ATT == 0 || ATT == 2 || ATT == 5 || ATT == 7 ? 128 : 256;
     static constexpr int U = CHUNK / (LA_WAVES * (64 / LPR));
     static constexpr int VS = ATT == 5 || ATT == 6 ? LPR / 4 : 1;
     static constexpr int LB = ATT == 1 || ATT == 6 ? 128 : 0;   // forms entered above position 127 only (bins > 128)
-    static constexpr int RING = att_ring(ATT);
 };
 
 // The eight pointers every block needs FIRST lead the argument list: built with kernel-argument preload (csrc/Makefile, ATTNFLAGS) they arrive in SGPRs with the
@@ -102,7 +119,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
         ho.pub = g_att;
         if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2, false, 1, AttShape<LPR, ATT>::LB>(a.att, (int)b, ho);
         else if constexpr (ATT == 5 || ATT == 6) attention_body<LPR, U, NW, 2, false, AttShape<LPR, ATT>::VS, AttShape<LPR, ATT>::LB>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
-        else attention_split_body<LPR, U, true, NW, AttShape<LPR, ATT>::RING>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
+        else attention_split_body<LPR, U, true, NW, typename AttLoad<ATT>::type>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
     } else {
         const unsigned j = b - a.natt;
         if constexpr (att_is_split(ATT)) {
@@ -136,13 +153,7 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
 #define Q4_AO_DISPATCH(LPR)                                                                                              \
     {                                                                                                                     \
         auto go = [&](auto kernel) -> int {                                                                               \
-            if (smem > 64 * 1024) {                                                                                       \
-                static size_t opted = 64 * 1024;                                                                          \
-                if (smem > opted) {                                                                                       \
-                    Q4_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                    opted = smem;                                                                                         \
-                }                                                                                                         \
-            }                                                                                                             \
+            { const int rc = lds_opt_in((const void*)kernel, smem); if (rc) return rc; }                                  \
             if (max_blocks_per_cu) {                                                                                      \
                 int n = 0;                                                                                                \
                 Q4_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)block.x, smem));                     \
@@ -161,9 +172,6 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             case 4: return go(attention_oproj_kernel<2, false, 4, LPR>);                                                  \
             case 5: return go(attention_oproj_kernel<2, false, 5, LPR>);                                                  \
             case 6: return go(attention_oproj_kernel<2, false, 6, LPR>);                                                  \
-            case 7: return go(attention_oproj_kernel<2, false, 7, LPR>);                                                  \
-            case 8: return go(attention_oproj_kernel<2, false, 8, LPR>);                                                  \
-            case 9: return go(attention_oproj_kernel<2, false, 9, LPR>);                                                  \
             case 16: return go(attention_oproj_kernel<3, true, 0, LPR>);                                                  \
             case 17: return go(attention_oproj_kernel<3, true, 1, LPR>);                                                  \
             case 18: return go(attention_oproj_kernel<3, true, 2, LPR>);                                                  \
@@ -171,9 +179,6 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             case 20: return go(attention_oproj_kernel<3, true, 4, LPR>);                                                  \
             case 21: return go(attention_oproj_kernel<3, true, 5, LPR>);                                                  \
             case 22: return go(attention_oproj_kernel<3, true, 6, LPR>);                                                  \
-            case 23: return go(attention_oproj_kernel<3, true, 7, LPR>);                                                  \
-            case 24: return go(attention_oproj_kernel<3, true, 8, LPR>);                                                  \
-            case 25: return go(attention_oproj_kernel<3, true, 9, LPR>);                                                  \
             case 32: return go(attention_oproj_kernel<4, false, 0, LPR>);                                                 \
             case 33: return go(attention_oproj_kernel<4, false, 1, LPR>);                                                 \
             case 34: return go(attention_oproj_kernel<4, false, 2, LPR>);                                                 \
@@ -181,9 +186,7 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             case 36: return go(attention_oproj_kernel<4, false, 4, LPR>);                                                 \
             case 37: return go(attention_oproj_kernel<4, false, 5, LPR>);                                                 \
             case 38: return go(attention_oproj_kernel<4, false, 6, LPR>);                                                 \
-            case 39: return go(attention_oproj_kernel<4, false, 7, LPR>);                                                 \
-            case 40: return go(attention_oproj_kernel<4, false, 8, LPR>);                                                 \
-            case 41: return go(attention_oproj_kernel<4, false, 9, LPR>);                                                 \
+            Q4_AO_LAB_CASES(LPR)                                                                                          \
         }                                                                                                                 \
         return Q4_ERR_UNSUPPORTED_SIZE;                                                                                   \
     }

@@ -15,6 +15,13 @@ __device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amd
 __device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+// Descriptor for a block's share of a tensor: based at the block's first byte and bounded at the tensor's end. The range check of a raw
+// buffer covers the lane's voffset (+ the immediate) only, NOT soffset: with the tensor's base in the descriptor and the block's start in
+// soffset, a 1 KiB piece that begins near the tensor's end reads up to 1 KiB past it (harmless inside a model's weight slab, a latent
+// fault for a caller whose tensor ends with its allocation). Based like this, lanes past the end are out of range: no memory request.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_from(const void* tensor, unsigned first_byte, unsigned tensor_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(tensor) + first_byte), 0, (int)(tensor_bytes - first_byte), 0x00020000);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // the same with a count that is a constant only after unrolling (0 .. 15; anything larger waits for 15: stronger, never wrong)

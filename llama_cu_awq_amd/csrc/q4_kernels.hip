@@ -291,7 +291,7 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 15) g_ao_hold_pct = slots;  // split-context bins: the o-proj role's weight requests held back this share of the K / V stream's estimated duration
     if (kind == 14) g_att_ring = slots;     // 0: the split-context attention role takes its K / V rows in registers, 1: on LDS-DMA rings (same bits)
     if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
-    if (kind == 11) g_engine = slots;       // the GEMV forms: 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings (gemv_engine.hip)
+    if (kind == 11) g_gemv_form = slots;    // a GemvForm (q4_internal.h): 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
 }
@@ -314,7 +314,7 @@ int q4_matmul_f16(q4_half* xout, const q4_half* x, const q4_half* w, int n, int 
     if ((n & 7) || (d & 7)) return Q4_ERR_UNSUPPORTED_SIZE;                         // llama2_q4.cu:215
     if (w_row_stride == -1) w_row_stride = n;                                       // :220
     if (w_row_stride & 7) return Q4_ERR_UNSUPPORTED_SIZE;
-    if (cls_strip_covers(n, d, batch, w_row_stride, alpha)) return launch_cls_strip(xout, x, nullptr, w, n, d, nullptr);   // the classifier's shape: same bits, streamed through LDS-DMA rings
+    if (cls_strip_covers(n, d, batch, w_row_stride, alpha)) return launch_cls_strip(xout, x, nullptr, w, n, d);   // the classifier's shape: same bits, streamed through LDS-DMA rings
     constexpr int ROWS = 2, WAVES = 4;
     dim3 grid(divUp(d, ROWS * WAVES), batch);
     if (n <= 2048)
@@ -406,12 +406,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
     const AttArgs aa = {output, q, key_cache, value_cache, head_size, kv_mul, kv_dim, pPos, alpha, max_seq_len, g_dbg};
 #define Q4_ATT(L)                                                                                                  \
     {                                                                                                              \
-        static size_t opted = 64 * 1024;   /* per instantiation: opt in to more LDS only when a launch needs more */ \
-        if (smem > opted) {                                                                                        \
-            Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)smem));                                                                \
-            opted = smem;                                                                                          \
-        }                                                                                                          \
+        { const int rc = lds_opt_in((const void*)attention_kernel<L>, smem); if (rc) return rc; }   /* only when a launch needs more than 64 KiB */ \
         Q4_LAUNCH((attention_kernel<L>), grid, block, smem, aa);                                                   \
     }
     switch (head_size) {
@@ -432,11 +427,7 @@ int launch_attention(q4_half* output, const q4_half* q, const q4_half* key_cache
             if (head_size < 8 || head_size > 256 || (head_size & 7)) return Q4_ERR_UNSUPPORTED_SIZE;
 #define Q4_ATT_PAD(L)                                                                                                       \
     {                                                                                                                       \
-        static size_t opted = 64 * 1024;                                                                                    \
-        if (smem > opted) {                                                                                                 \
-            Q4_HIP(hipFuncSetAttribute((const void*)attention_kernel<L, 4, ATT_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-            opted = smem;                                                                                                   \
-        }                                                                                                                   \
+        { const int rc = lds_opt_in((const void*)attention_kernel<L, 4, ATT_NW, true>, smem); if (rc) return rc; }         \
         Q4_LAUNCH((attention_kernel<L, 4, ATT_NW, true>), grid, block, smem, aa);                                           \
     }
             if (head_size < 32) Q4_ATT_PAD(4) else if (head_size < 64) Q4_ATT_PAD(8) else if (head_size < 128) Q4_ATT_PAD(16) else Q4_ATT_PAD(32)
@@ -505,24 +496,22 @@ int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pP
 namespace q4 {
 // tail != nullptr: the caller's next launch would be the greedy sampler with these arguments; *folded says whether this launch took it over
 // (only the strips form does: gemv_strip_cls.h)
-// Measured (7B and 13B -n 256, interleaved in one process, three calls): 967.6 / 967.1, 968.7 / 968.3, 550.8 / 551.0 tokens/s without / with -- the
-// epilogue's chain behind the last block (candidate written through and acknowledged, returning arrival, 2 KB of candidates, token ring over PCIe)
-// costs what the 6 us launch and its boundary cost. Bit-identical and NOT shipped: profiling knob 12.
-#ifdef Q4_PROFILING
-int g_cls_argmax = 0;
-#else
-enum { g_cls_argmax = 0 };
-#endif
+// the LDS opt-in is not a stream operation: q4_set_device and build_transformer make it (q4_runtime.hip), outside any capture
+int cls_strip_prepare() {
+    int rc = Q4_OK;     // (once per device: lds_opt_in)
+    if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<8, true, CLS_D>, StripClsLds<8, CLS_D>::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<8, false, CLS_D>, StripClsLds<8, CLS_D>::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<10, true, CLS_D>, StripClsLds<10, CLS_D>::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<10, false, CLS_D>, StripClsLds<10, CLS_D>::BYTES);
+    return rc;
+}
+// (the greedy sampler as this launch's epilogue -- bit-identical, measured level, not shipped -- is exp/cls_argmax.h: it answers through g_lab)
 int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded) {
     if (folded) *folded = false;
     if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) {
-        if (tail && folded && g_cls_argmax && tail->words && (unsigned)cu_count() <= CLS_SYNC_BLOCKS) {
-            const ClsArgmax am = {tail->words, reinterpret_cast<unsigned long long*>(tail->words + 2), tail->result, tail->pPos, tail->pPosGpu, tail->write_token,
-                                  tail->x_next, tail->table, dim};
-            *folded = true;
-            return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab, &am);
-        }
-        return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab, nullptr);
+        int rc = Q4_OK;
+        if (tail && folded && g_lab.cls_argmax && g_lab.cls_argmax(logits, x, rms_w, wcls, dim, vocab, tail, &rc)) { *folded = true; return rc; }
+        return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab);
     }
     const int rc = q4_rmsnorm(x, x, rms_w, dim);
     return rc ? rc : q4_matmul_f16(logits, x, wcls, dim, vocab, 1, 0, 0, 0, -1, 1.0f);

@@ -78,6 +78,19 @@ static int clear_handoff_state(const RunState* s, bool error_too) {
     return Q4_OK;
 }
 
+int lds_opt_in(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return Q4_OK;
+    static std::map<std::pair<const void*, int>, size_t> opted;
+    int dev = 0;
+    Q4_HIP(hipGetDevice(&dev));
+    size_t& have = opted[{kernel, dev}];
+    if (bytes > have) {
+        Q4_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return Q4_OK;
+}
+
 // graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
 static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][16];   // [bin][variant | 8: Q4_MULTI_STEPS steps per graph]
 static bool g_captured[Q4_MAX_GRAPHS][16];
@@ -186,7 +199,10 @@ void q4_set_fusion(int level) {
         for (auto& kv : g_sync_by_state) (void)clear_handoff_state(kv.first, false);   // no stale counters / granules across a change of launch sequence
 }
 int q4_get_fusion(void) { return g_fusion; }
-void q4_set_use_graphs(int enable) { g_use_graphs = enable ? 1 : 0; }
+// 1: captured graphs (USE_CUDA_GRAPHS, llama2_q4.cu:33); 0: eager launches with the exact context length (the reference's other path, :374);
+// 2: eager launches with the graph path's sequence-length BIN -- what the graphs run, one launch at a time: the mode to profile in
+// (rocprofv3 cannot trace inside a graph capture; with 0 the attention launch picks its form from the context length, not from the bin)
+void q4_set_use_graphs(int enable) { g_use_graphs = enable == 2 ? 2 : enable ? 1 : 0; }
 void q4_set_quiet(int quiet) { g_quiet = quiet; }
 
 void q4_reset_graphs(void) {
@@ -486,6 +502,15 @@ static inline void arm_timing(int bit) {
 
 static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding, GreedyTail* tail = nullptr,
                        bool* folded = nullptr);
+#ifdef Q4_PROFILING
+// tools/error_growth.py: the residual stream after the attention half and after the FFN half of every layer, [n_layers][2][dim] halves on
+// the device (eager launches only: a copy node would be baked into captured graphs)
+static q4_half* g_layer_dump = nullptr;
+extern "C" void q4_set_layer_dump(void* p) { g_layer_dump = (q4_half*)p; }
+#define Q4_LAYER_DUMP(half_) do { if (g_layer_dump) Q4_HIP(hipMemcpyAsync(g_layer_dump + (size_t)(2 * l + (half_)) * dim, x, (size_t)dim * sizeof(q4_half), hipMemcpyDeviceToDevice, g_stream)); } while (0)
+#else
+#define Q4_LAYER_DUMP(half_) do { } while (0)
+#endif
 int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin) {
     return run_network(pPos, p, s, w, seq_len_bin, false);
 }
@@ -541,6 +566,7 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
                                       att_bytes, sync && p->n_heads <= SYNC_MAX_HEADS ? sync + SYNC_ARRIVE : nullptr));   // :320
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
         }
+        Q4_LAYER_DUMP(0);
         if (g_fusion) {
             Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
         } else {
@@ -548,6 +574,7 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
             Q4_TRY(q4_ffn_matvec_silu(s->hb, s->xb, &L->wq_gate, &L->wq_up, dim, hidden_dim));         // :329
         }
         Q4_UNLESS(16, q4_matmul_q4(s->x, s->hb, &L->wq_down, hidden_dim, dim, 1, -1, nullptr));        // :332
+        Q4_LAYER_DUMP(1);
     }
     if (g_fusion >= 1) {      // one launch where the classifier runs as strips (gemv_strip_cls.h): the final norm inside its x staging
         if (tail) tail->words = sync ? sync + cls_sync_offset(dim) : nullptr;
@@ -632,6 +659,11 @@ static int coin_ring_for(const Sampler* sampler, int positions, CoinRing** out) 
         r = CoinRing{nullptr, nullptr, 0};
         Q4_HIP(hipHostMalloc((void**)&r.host, (size_t)positions * sizeof(float), hipHostMallocDefault));
         Q4_HIP(hipMalloc((void**)&r.dev, (size_t)positions * sizeof(float)));
+        // zeroed on both sides: a caller whose `pos` runs behind the device position (q4_run_transformer_at / _steps with a stale `pos`: the
+        // sampled step reads coins[device position], the host fills ring[pos + i]) then samples with coin 0.0 -- the most probable token,
+        // deterministic -- instead of with uninitialised memory. INTEGRATION.md: `pos` must equal the device position for sampled steps.
+        memset(r.host, 0, (size_t)positions * sizeof(float));
+        Q4_HIP(hipMemsetAsync(r.dev, 0, (size_t)positions * sizeof(float), g_stream));
         r.cap = positions;
     }
     *out = &r;
@@ -725,10 +757,10 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
     const bool greedy = sampler_is_greedy(pSampler, gen_token);
     int seq_len_bin;
     const int graphIndex = graph_bin(seq_len, p, &seq_len_bin);
-    if (nsteps != 1 && (nsteps != g_multi_steps || !g_use_graphs)) return Q4_ERR_ARG;
+    if (nsteps != 1 && (nsteps != g_multi_steps || g_use_graphs != 1)) return Q4_ERR_ARG;
     if (pos < 0 || pos + nsteps > p->seq_len) return Q4_ERR_ARG;
 
-    if (g_use_graphs) {
+    if (g_use_graphs == 1) {
         if (g_graph_owner != (const void*)s) { q4_reset_graphs(); g_graph_owner = s; }
         // Unlike the reference, the greedy sampler kernel and the fp32 logits copy are part of the captured
         // graph (one launch per token instead of up to three); the variant index keeps them apart.
@@ -790,7 +822,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
     }
     GreedyTail tail = {nullptr, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token, nullptr, w->token_embedding_table};
     bool folded = false;
-    Q4_TRY(run_network(s->pos, p, s, w, seq_len, false, greedy && !copyLogits ? &tail : nullptr, &folded));   // :374
+    Q4_TRY(run_network(s->pos, p, s, w, g_use_graphs == 2 ? seq_len_bin : seq_len, false, greedy && !copyLogits ? &tail : nullptr, &folded));   // :374
     if (copyLogits) Q4_TRY(q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos));   // :377-382
     return sample_impl(pSampler, s, gen_token, !folded);
 }
@@ -813,7 +845,7 @@ int q4_shared_pos(const RunState* s) { return s->shared_data->pos; }
 // bin; else 1.
 int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p, const Sampler* sampler) {
     const int k = g_multi_steps;
-    if (k <= 1 || !g_use_graphs || pos + k > steps || pos + k > p->seq_len) return 1;
+    if (k <= 1 || g_use_graphs != 1 || pos + k > steps || pos + k > p->seq_len) return 1;
     const bool gen0 = pos >= num_prompt_tokens - 1, gen1 = pos + k - 1 >= num_prompt_tokens - 1;
     if (gen0 != gen1) return 1;
     (void)sampler;     // sampled steps take their coins from a device ring by position: they go out k per replay too

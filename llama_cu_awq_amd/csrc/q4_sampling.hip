@@ -556,13 +556,8 @@ extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_prepare(Samp
         Q4_HIP(hipMalloc(&sampler->tempStorage_sort, bytes));
         sampler->temp_storage_bytes_sort = bytes;
     }
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
-        Q4_HIP(hipFuncSetAttribute((const void*)topp_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP_T * SMP_E * 4 + 256 * SMP_W * 4));
-        lds_opt_in = true;
-    }
-    return Q4_OK;
+    const int rc = q4::lds_opt_in((const void*)topp_sample_kernel<false>, SMP_T * SMP_E * 4 + 256 * SMP_W * 4);      // (once per device)
+    return rc ? rc : q4::lds_opt_in((const void*)topp_sample_kernel<true>, SMP_T * SMP_E * 4 + 256 * SMP_W * 4);
 }
 
 extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampler* sampler, RunState* s, float coin, const float* coins,
@@ -577,7 +572,9 @@ extern "C" __attribute__((visibility("hidden"))) int q4_sample_topp_device(Sampl
     int* v0 = (int*)(base + 2 * kb); int* v1 = (int*)(base + 2 * kb + vb);
     const size_t smem = (n <= SMP_T * SMP_E ? (size_t)SMP_T * SMP_E * 4 : 0) + 256 * SMP_W * 4;
     float* wave_total = (float*)sampler->tempStorage_scan;
-    if (n <= SMP_T * SMP_E && (n & 7) == 0) {      // the softmax over 16 CUs, then normalise + search on one
+    // (the spread softmax takes max(logit) / T for the maximum of the scaled logits: true for T > 0 only. A negative temperature -- the CLI clamps it,
+    // the C / Python API does not -- goes the one-block way, which like the reference takes the maximum of the scaled values and stays finite)
+    if (n <= SMP_T * SMP_E && (n & 7) == 0 && sampler->temperature > 0.0f) {      // the softmax over 16 CUs, then normalise + search on one
         Q4_LAUNCH(softmax_spread_kernel, dim3(SMX_B), dim3(SMP_T), 0, s->logits, n, sampler->temperature, k0, wave_total);
         Q4_LAUNCH(topp_sample_kernel<true>, dim3(1), dim3(SMP_T), smem, s->logits, n, sampler->temperature, do_sort, coin, coins, sampler->topp,
                   sampler->indices, k0, v0, k1, v1, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, x_next, table, dim, wave_total);

@@ -103,6 +103,8 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.orc_forward.restype = None
     L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_set_layer_dump.restype = None
+    L.orc_set_layer_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_forward_f64.restype = C.c_int
     L.orc_forward_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.orc_generate_greedy.restype = C.c_int
@@ -205,6 +207,18 @@ class Model:
     def forward(self, token, pos):
         self.L.orc_forward(self.h, token, pos)
         return self.logits()
+
+    def layer_dump(self, on=True):
+        """tools/error_growth.py: keep the residual stream after each half layer of the last forward / forward_f64 call:
+        returns (f16 [n_layers, 2, dim], f64 [n_layers, 2, dim]) arrays that the following calls fill."""
+        if not on:
+            self.L.orc_set_layer_dump(self.h, None, None)
+            self._d16 = self._d64 = None
+            return None
+        self._d16 = np.zeros((self.cfg.n_layers, 2, self.cfg.dim), dtype=np.float16)
+        self._d64 = np.zeros((self.cfg.n_layers, 2, self.cfg.dim), dtype=np.float64)
+        self.L.orc_set_layer_dump(self.h, self._d16.ctypes.data, self._d64.ctypes.data)
+        return self._d16, self._d64
 
     def forward_f64(self, token, pos, cap=32):
         """The same network function evaluated in double without any intermediate rounding (the yardstick for two

@@ -61,6 +61,10 @@ typedef struct {
     /* unrounded evaluation (orc_forward_f64): double KV cache for the first f64_cap positions */
     double *k64, *v64;
     int f64_cap;
+    /* tools/error_growth.py: the residual stream after the attention half (o-proj + residual) and after the FFN half (down + residual)
+     * of every layer of the LAST forward, [n_layers][2][dim]; null = off */
+    f16 *dump16;
+    double *dump64;
 } OrcModel;
 
 /* ---- fp16 <-> fp32, exact IEEE binary16, round-to-nearest-even ------------- */
@@ -580,6 +584,7 @@ f16 *orc_x(OrcModel *m) { return m->x; }
 f16 *orc_key_cache(OrcModel *m) { return m->key_cache; }
 f16 *orc_value_cache(OrcModel *m) { return m->value_cache; }
 void orc_reset(OrcModel *m) { m->pos = 0; }
+void orc_set_layer_dump(OrcModel *m, f16 *dump16, double *dump64) { m->dump16 = dump16; m->dump64 = dump64; }
 
 /* ---- a15: run_llama_network, llama2_q4.cu:286-340: one token at position pos --- */
 void orc_forward(OrcModel *m, int token, int pos) {
@@ -601,10 +606,12 @@ void orc_forward(OrcModel *m, int token, int pos) {
         orc_attention_bin(m->xb, m->q, m->key_cache + loff, m->value_cache + loff, m->att, p->n_heads, head_size, kv_mul, pos,
                           orc_seq_len_bin(pos, p->seq_len));                  /* :320, bin from run_transformer :354-360 */
         orc_matmul_q4(m->x, m->xb, L->o.weight, L->o.zeros, L->o.scales, dim, dim, 1, -1, 0);        /* :323 */
+        if (m->dump16) memcpy(m->dump16 + (size_t)(2 * l) * dim, x, (size_t)dim * 2);
         orc_rmsnorm(m->xb, x, L->rms_ffn, dim);                               /* :326 */
         orc_ffn_matvec_silu(m->hb, m->xb, L->gate.weight, L->gate.zeros, L->gate.scales,
                             L->up.weight, L->up.zeros, L->up.scales, dim, hidden_dim);              /* :329 */
         orc_matmul_q4(m->x, m->hb, L->down.weight, L->down.zeros, L->down.scales, hidden_dim, dim, 1, -1, 0); /* :332 */
+        if (m->dump16) memcpy(m->dump16 + (size_t)(2 * l + 1) * dim, x, (size_t)dim * 2);
     }
     orc_rmsnorm(x, x, m->rms_final, dim);                                     /* :336 (in place) */
     orc_matmul_f16(m->logits, x, m->wcls, p->dim, p->vocab_size, 1.0f);       /* :339 */
@@ -694,11 +701,13 @@ int orc_forward_f64(OrcModel *m, int token, int pos, int cap, double *logits_out
             }
         }
         matvec_q4_f64(x, xb, &L->o, dim, dim, 1);
+        if (m->dump64) memcpy(m->dump64 + (size_t)(2 * l) * dim, x, (size_t)dim * sizeof(double));
         rmsnorm_f64(xb, x, L->rms_ffn, dim);
         matvec_q4_f64(hb, xb, &L->gate, dim, hidden, 0);
         matvec_q4_f64(hb2, xb, &L->up, dim, hidden, 0);
         for (int i = 0; i < hidden; i++) hb[i] = hb[i] / (1.0 + exp(-hb[i])) * hb2[i];   /* gpu_kernels.h:271-272 */
         matvec_q4_f64(x, hb, &L->down, hidden, dim, 1);
+        if (m->dump64) memcpy(m->dump64 + (size_t)(2 * l + 1) * dim, x, (size_t)dim * sizeof(double));
     }
     rmsnorm_f64(xb, x, m->rms_final, dim);
 #pragma omp parallel for schedule(static)

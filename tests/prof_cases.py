@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     """The fused gate/up GEMV at K = 4096 has three forms (knob 11): -1 = gemv_q4_kernel<MODE_FFN> (the wave-owned kernel), 8 .. 14 = "strips"
     (csrc/gemv_strip.h: sixteen self-loading waves per CU on LDS-DMA rings; ring depth 2 / 4 / 8, plain and paced issue), 1 .. 6 = the
-    loader / consumer engine (csrc/gemv_engine.hip: one loader wave, eight consumer waves, an 8 x 16 KiB ring; vmcnt lag, + 4 with the
+    loader / consumer engine (csrc/exp/ffn_engine.h: one loader wave, eight consumer waves, an 8 x 16 KiB ring; vmcnt lag, + 4 with the
     consumers' next-slot prefetch); 0 = the product's choice (strips from 36 columns per CU on, i.e. for 11008 and 14336 here). Same arithmetic in
     the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split over the CUs and the smallest covered width,
     repeated launches (a race between a fill and a read would show as a run-to-run difference)."""
@@ -379,7 +379,7 @@ def test_greedy_sampler_inside_the_classifier_launch(q4, tmp_path, name, graphs)
 @pytest.mark.parametrize("fusion", [3, 1])
 def test_qkv_strips_equal_the_wave_owned_kernel(q4, tmp_path, model, steps, fusion):
     """The fused q/k/v launch of the 13B shape (K = N = 5120, head 128: rmsnorm + three GEMVs + RoPE + KV write) runs as strips
-    (csrc/gemv_strip_qkv.h: ten RoPE pairs per CU, dword-granular LDS-DMA gathers of scales and zeros, the (cos, sin) entries
+    (csrc/exp/qkv_strip.h: ten RoPE pairs per CU, dword-granular LDS-DMA gathers of scales and zeros, the (cos, sin) entries
     requested between the ring's first pieces; measured slower than the wave-owned kernel and therefore not the product's choice). Knob
     11 = -1 forces gemv_q4_kernel<MODE_QKV, 3, 4, true, 0, 1, true> everywhere, 0 is the product (the same kernel for this launch), 8 strips
     wherever covered. Same arithmetic in the same order: logits AND every K / V row written must agree bit for bit, with

@@ -32,7 +32,8 @@ def test_matmul_q4_plain(q4, orc, rng, K, N):
     assert_close_f16(dout.get(np.float16, N), ref16, ref64, what="plain %dx%d" % (K, N))
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (352, 256), (28672, 8192)])
+# (13824, 5120) and (14336, 4096): the accumulating down projections that run as strips (csrc/gemv_strip_down.h, down_strip_kernel<4, true>)
+@pytest.mark.parametrize("K,N", [(4096, 4096), (11008, 4096), (352, 256), (28672, 8192), (13824, 5120), (14336, 4096)])
 def test_matmul_q4_accum(q4, orc, rng, K, N):
     w, z, s, x = _mk(rng, K, N)
     old = rng.standard_normal(N).astype(np.float16)
@@ -76,7 +77,7 @@ def test_ffn_matvec_silu(q4, orc, rng, K, N):
     assert_close_f16(dout.get(np.float16, N), ref16, max_ulp=2, max_frac=0.06, what="ffn %dx%d" % (K, N))
 
 
-@pytest.mark.parametrize("dim", [4096, 256])
+@pytest.mark.parametrize("dim", [4096, 256, 5120])      # 5120: K in two k-slots and a shared half slot (gpu_kernels.h:213-254)
 def test_qkv_matvec(q4, orc, rng, dim):
     seq, pos, layer = 6, 3, 1
     mats = [synth.random_qweight(rng, dim, dim) for _ in range(3)]
@@ -122,3 +123,51 @@ def test_linearity_full_size(q4, rng):
     q4.synchronize()
     a, b = o1.get(np.float16, N).astype(np.float32), o2.get(np.float16, N).astype(np.float32)
     assert np.array_equal(a * 2, b)
+
+
+class _TailQWeight:
+    """A QWeight whose zeros and scales tensors END with their device allocations (sized in whole 2 MiB pages, the tensor flush against
+    the end): a kernel that reads past a tensor's end leaves the allocation."""
+
+    def __init__(self, q4, weight, zeros, scales):
+        import ctypes as C
+        self.bufs = [q4.DevBuf(weight)]
+        ptrs = []
+        for arr in (zeros, scales):
+            arr = np.ascontiguousarray(arr)
+            total = -(-arr.nbytes // (2 << 20)) * (2 << 20)
+            buf = q4.DevBuf(nbytes=total)
+            self.bufs.append(buf)
+            ptr = buf.ptr + total - arr.nbytes
+            q4.check(q4.lib().q4_memcpy_h2d(ptr, arr.ctypes.data, arr.nbytes))
+            ptrs.append(ptr)
+        self.q = q4.QWeight(self.bufs[0].ptr, ptrs[0], ptrs[1])
+        self._C = C
+
+    def ref(self):
+        return self._C.byref(self.q)
+
+
+@pytest.mark.parametrize("kind,K,N", [("ffn", 4096, 11008), ("ffn", 5120, 13824), ("down", 13824, 5120), ("down", 14336, 4096), ("ffn", 4096, 12552)])
+def test_strips_side_data_stays_inside_tensors_that_end_with_their_allocation(q4, orc, rng, kind, K, N):
+    """The strips kernels fetch their block's scales and zeros as 1 KiB LDS-DMA pieces. The last block's pieces must not reach past the
+    tensors (round 4 based the descriptor at the tensor and put the block's start in soffset, which the hardware's range check does
+    not cover: up to 3 KiB past the end). Results must equal the oracle with every side tensor flush against the end of its allocation."""
+    x = rng.standard_normal(K).astype(np.float16)
+    if kind == "ffn":
+        g, u = synth.random_qweight(rng, K, N), synth.random_qweight(rng, K, N)
+        ref = orc.ffn_matvec_silu(x, g, u, K, N)
+        dg, du = _TailQWeight(q4, *g), _TailQWeight(q4, *u)
+        dx, dout = q4.DevBuf(x), q4.DevBuf(nbytes=N * 2)
+        q4.ffn_matvec_silu(dout, dx, dg, du, K, N)
+        q4.synchronize()
+        assert_close_f16(dout.get(np.float16, N), ref, max_ulp=2, max_frac=0.06, what="ffn %dx%d, tensors at allocation ends" % (K, N))
+    else:
+        w, z, s = synth.random_qweight(rng, K, N)
+        old = rng.standard_normal(N).astype(np.float16)
+        ref = orc.matmul_q4(x, w, z, s, K, N, accum_into=old)
+        dw = _TailQWeight(q4, w, z, s)
+        dx, dout = q4.DevBuf(x), q4.DevBuf(old)
+        q4.matmul_q4(dout, dx, dw, K, N, accum=True)
+        q4.synchronize()
+        assert_close_f16(dout.get(np.float16, N), ref, what="down %dx%d, tensors at allocation ends" % (K, N))

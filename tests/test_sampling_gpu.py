@@ -103,6 +103,31 @@ def test_sample_matches_restatement_at_production_vocab(q4, orc, big_vocab_model
     t.close()
 
 
+@pytest.mark.parametrize("temperature,topp", [(-0.7, 0.9), (-1.5, 1.0)])
+def test_negative_temperature_through_the_api_stays_finite(q4, orc, big_vocab_models, temperature, topp):
+    """build_sampler does not clamp the temperature (only the CLI does, llama2_q4.cu:682): with T < 0 the reference's softmax still
+    takes the maximum of the SCALED logits (gpu_kernels.h:511,522-531) and stays finite. The 16-CU spread softmax derives that maximum
+    from max(logit) / T, which holds for T > 0 only, so such a sampler goes the one-block way: token-exact against the restatement."""
+    L = q4.lib()
+    t = q4.Transformer(big_vocab_models["v32k"], temperature=temperature, topp=topp, seed=5)
+    vocab = t.config.vocab_size
+    rng = np.random.default_rng(77)
+    state = C.c_ulonglong(5)
+    bad = []
+    for trial in range(21):
+        logits = _logit_case(rng, vocab, trial)
+        t.reset([1])
+        q4.check(L.q4_memcpy_h2d(t.state.contents.logits, logits.ctypes.data, logits.nbytes))
+        q4.check(L.q4_sample(t.sampler, t.state, 1))
+        q4.synchronize()
+        coin = L.random_f32(C.byref(state))
+        ref = orc.lib().orc_sample_topp(orc.f16_bits(logits.copy()), vocab, temperature, topp, coin)
+        if t.token(1) != ref:
+            bad.append((trial, trial % 7, int(t.token(1)), ref, coin))
+    assert not bad, bad[:8]
+    t.close()
+
+
 @pytest.mark.parametrize("temperature,topp", [(0.5, 0.6), (1.0, 0.9), (0.8, 1.0), (0.05, 0.9)])
 def test_sampled_steps_inside_the_graph_equal_the_stepwise_sampler(q4, model, temperature, topp):
     """Sampled generation goes out eight steps per graph replay: topp_sample_kernel is part of the captured graph, reads its

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step A of the loader / consumer engine (csrc/gemv_engine.hip) against the shipped gate/up kernel, in ONE process:
+"""Step A of the loader / consumer engine (csrc/exp/ffn_engine.h) against the shipped gate/up kernel, in ONE process:
 bit equality of q4_ffn_matvec_silu and of the norm-fused launch on the 7B geometry, then per-launch time (HIP events
 and inside a hipGraph) and tokens/s for knob 11 = -1 (gemv_q4_kernel), 0 (the product's choice), 1..3 (engine, vmcnt lag), 5, 6 (lag 1, 2 with the
 consumers' next-slot prefetch), 8..14 (strips variants, csrc/gemv_strip.h).  ENGINE_VARIANTS=1,5 tools/engine_check.py [model]"""

@@ -18,7 +18,7 @@ api.check(L.q4_set_device(0))
 s = C.c_void_p()
 api.check(L.q4_stream_create(C.byref(s)))
 L.q4_set_stream(s)
-L.q4_set_use_graphs(0)
+L.q4_set_use_graphs(2)     # eager launches with the graph path's bins: every attention form on the positions the graphs run it for
 if len(sys.argv) > 3:
     L.q4_set_fusion(int(sys.argv[3]))
 tr = api.Transformer(path)

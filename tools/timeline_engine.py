@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wall-clock timeline (s_memrealtime, 10 ns ticks) of the loader / consumer gate/up engine (csrc/gemv_engine.hip), per block:
+"""Wall-clock timeline (s_memrealtime, 10 ns ticks) of the loader / consumer gate/up engine (csrc/exp/ffn_engine.h), per block:
 when the loader knows each fill landed, when consumer wave 0 sees and finishes each slot.  tools/timeline_engine.py [lag]"""
 import ctypes as C, os, sys
 import numpy as np

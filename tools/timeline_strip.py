@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wall-clock timeline (s_memrealtime, 10 ns ticks) of the "strips" form of the gate/up GEMV (csrc/gemv_engine.hip, knob 11 = 8..14),
+"""Wall-clock timeline (s_memrealtime, 10 ns ticks) of the "strips" form of the gate/up GEMV (csrc/gemv_strip.h; variants csrc/exp/ffn_strip_variants.h, knob 11 = 8..14),
 per block: x chain of wave 0, when every wave's first piece landed and when it finished.  tools/timeline_strip.py [setting]"""
 import ctypes as C, os, sys
 import numpy as np
