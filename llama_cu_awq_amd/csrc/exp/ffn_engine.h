@@ -158,7 +158,9 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
             ss = rms_scale_from_partials<KSL * 256>(part, KSL * 256, a.K);
         }
         u32x4 v = xraw;
-        if (NORM) v = rms_apply8(v, wraw, ss);
+        const unsigned sgn = q4_stage_sign_bits(tid);      // odd units are staged negated (gemv_q4.h, q4_stage_sign_bits)
+        if (NORM) v = rms_apply8(v, wraw, q4_signed_scale(ss, sgn));
+        else v = q4_signed_x(v, sgn);
         const u32x4 pv = permute_x8(v);
         const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
         float cb = 0.f;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__((ENG_CONSUMERS + 1) * 64) ffn_engine_kernel(co
                 if (STAMPS && wave == 0) { asm volatile("" : "+v"(c)); ENG_STAMP(31 + i); }
             }
         }
-        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: the column of slot g4 * 4 + r
+        const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: the column of slot g4 * 4 + r
         const int row = lane >> 4;
         if ((lane & 15u) == 0 && g4 * 4 + row < nq) tot[(g4 * 4 + row) * 8 + wave] = total;
     }

@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_variant_kernel(con
         float ss = 1.f;
         if (NORM) ss = rms_scale_from_partials<TS * 256>(part, TS * 256, a.K);
         u32x4 v = xraw;
-        if (NORM) v = rms_apply8(v, wraw, ss);
+        const unsigned sgn = q4_stage_sign_bits(tid);      // odd units are staged negated (gemv_q4.h, q4_stage_sign_bits)
+        if (NORM) v = rms_apply8(v, wraw, q4_signed_scale(ss, sgn));
+        else v = q4_signed_x(v, sgn);
         const u32x4 pv = permute_x8(v);
         const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
         float cb = 0.f;
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_variant_kernel(con
                 if (STAMPS) { asm volatile("" : "+v"(c)); if (wave == 0 && i < 8) SSTAMP(4 + i); if (i == nu - 1) SSTAMP(48 + wave); }
             }
         }
-        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit g4 * 4 + r
+        const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit g4 * 4 + r
         const int row = lane >> 4;
         if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wv + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
     }

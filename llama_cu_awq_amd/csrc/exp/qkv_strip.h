@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) qkv_strip_kernel(const u32x4
         float ss = 1.f;
         if (NORM) ss = rms_scale_from_partials<TS * 256>(part, TS * 256, a.K);
         u32x4 v = xraw;
-        if (NORM) v = rms_apply8(v, wraw, ss);
+        const unsigned sgn = q4_stage_sign_bits(tid);      // odd units are staged negated (gemv_q4.h, q4_stage_sign_bits)
+        if (NORM) v = rms_apply8(v, wraw, q4_signed_scale(ss, sgn));
+        else v = q4_signed_x(v, sgn);
         const u32x4 pv = permute_x8(v);
         const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
         float cb = 0.f;
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) qkv_strip_kernel(const u32x4
     // ---- gemv_q4.h's MODE_QKV epilogue: row r of the wave holds unit r's total; RoPE on the fp16-rounded outputs of q and k
     q4_half* out = a.out[mat];
     if (mat != 0) out += (size_t)a.loff + (size_t)pos * a.N;                          // gpu_kernels.h:251,253
-    const float mine = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
+    const float mine = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
     float r = mine;
     if (roped) {
         const float other = round_h(__shfl_xor(mine, 32));

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
             const unsigned u = tid + (unsigned)i * (SD_WAVES * 64u);
             u32x4 v = xraw[i];
             if (u >= nchunks) v = (u32x4){0u, 0u, 0u, 0u};
+            v = q4_signed_x(v, q4_stage_sign_bits(tid));      // odd units are staged negated (gemv_q4.h, q4_stage_sign_bits)
             const u32x4 pv = permute_x8(v);
             float cb = 0.f;
 #pragma unroll
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(SD_WAVES * 64) down_strip_kernel(const u32x4* 
         }
     }
     {
-        const float total = reduce4_rows(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit r of this wave
+        const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;   // row r: unit r of this wave
         const int row = lane >> 4;
         if ((lane & 15u) == 0 && row < nu) tot[wave + SD_WAVES * row] = total;      // [column][part] = unit index
     }

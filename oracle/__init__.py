@@ -103,6 +103,8 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p]
     L.orc_forward.restype = None
     L.orc_forward.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_set_order_variant.restype = None
+    L.orc_set_order_variant.argtypes = [C.c_int]
     L.orc_set_layer_dump.restype = None
     L.orc_set_layer_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_forward_f64.restype = C.c_int

@@ -159,12 +159,21 @@ static float block_sum1024(float *v) {
 
 /* ---- a2: get_mat_vec_int4, reference gpu_kernels.h:171-210 ------------------ */
 /* lane-partitioned fp32 order exactly as the reference's 32-lane warp */
+/* tools/error_growth.py control: 1 = another VALID fp32 order of the same sums (each lane walks its groups from the last to the first, the 32
+ * lane sums are added sequentially instead of by the shuffle tree) -- how far apart do two legitimate orders of the reference's own arithmetic
+ * end up after 32 layers? 0 (always, outside that tool) = the reference's order. */
+static int g_order_variant = 0;
+void orc_set_order_variant(int v) { g_order_variant = v; }
+
 float orc_dot_q4(int index, const f16 *input, const uint32_t *qw, const uint32_t *qz, const f16 *sc,
                  int inputElements, int pzh, int sh, int pwh) {
     float lane[32];
     for (int tx = 0; tx < 32; tx++) {
         float sum = 0.f;
-        for (int ygq = 0; ygq * 128 + tx * 4 < pwh; ygq++) {                  /* :176 */
+        int nq = 0;
+        while (nq * 128 + tx * 4 < pwh) nq++;
+        for (int it = 0; it < nq; it++) {                                     /* :176 */
+            const int ygq = g_order_variant ? nq - 1 - it : it;
             uint32_t packed_q_z = qz[(size_t)index * pzh + ygq];              /* :177 */
             const uint32_t *lw = &qw[(size_t)index * pwh + ygq * 128 + tx * 4]; /* :181 */
             int group_y = ygq * 8 + (tx / 4);                                 /* :183 */
@@ -185,6 +194,11 @@ float orc_dot_q4(int index, const f16 *input, const uint32_t *qw, const uint32_t
             }
         }
         lane[tx] = sum;
+    }
+    if (g_order_variant) {
+        float t = 0.f;
+        for (int tx = 31; tx >= 0; tx--) t += lane[tx];
+        return t;
     }
     return warp_sum32(lane);                                                  /* :205-207 */
 }

@@ -223,14 +223,17 @@ def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, mod
             t = q4.Transformer(path)
             t.reset([1, 5, 9])
             got = []
+            every = {}
             for pos in range(steps):
                 t.run_transformer(pos >= 2)
-                if pos in cps:
+                if pos in cps or (model == "7b" and pos >= 2):
                     q4.synchronize()
-                    got.append(t.logits().copy())
+                    every[pos] = t.logits().copy()
+                    if pos in cps:
+                        got.append(every[pos])
             q4.check(L.q4_handoff_status(t.state))
             assert L.q4_handoff_timeouts() == 0 and L.q4_get_fusion() == lvl
-            outs[lvl] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            outs[lvl] = (got, [int(t.token(i)) for i in range(steps + 1)], every)
             t.close()
             L.q4_set_stream(full)
             q4.check(L.q4_stream_destroy(s))
@@ -240,7 +243,11 @@ def test_handoff_makes_progress_with_fewer_resident_blocks_than_the_grid(q4, mod
         L.q4_set_fusion(q4.DEFAULT_FUSION)
     for a, b, pos in zip(outs[1][0], outs[3][0], cps):
         if outs[1][1][:pos + 1] != outs[3][1][:pos + 1]:
-            assert pos > 60, "token rings diverged early (%d)" % pos
+            # the two levels are two valid fp32 groupings: their greedy rings may part, but only where the two best logits nearly tie
+            first = next(i for i, (x, y) in enumerate(zip(outs[1][1], outs[3][1])) if x != y)      # token first written by step first - 1
+            assert first - 1 in outs[1][2], "token rings diverged at %d (no logits kept there)" % first
+            top2 = np.sort(outs[1][2][first - 1].astype(np.float32))[-2:]
+            assert top2[1] - top2[0] <= 4e-3 * max(1.0, abs(top2[1])), "token rings diverged at %d without a near-tie (%g vs %g)" % (first, top2[1], top2[0])
             break
         af, bf = a.astype(np.float64), b.astype(np.float64)      # (another fp32 grouping of the positions: the model's bound;
         err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())   # 32 layers of the 7B geometry amplify a few ulps)

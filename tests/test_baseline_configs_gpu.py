@@ -32,6 +32,12 @@ MODEL_DIR = os.environ.get("Q4_MODEL_DIR", "/tmp")
 # logits vs the reference-order restatement, max |d| / max(1, |logit|), per geometry: 2x the worst value the round's runs measured
 # (profiles/r04_parity_observed.json: 7B 0.050 over 32 positions and 0.033 at the config-4 checkpoints, 13B 0.068 over 24 positions
 # and 0.051 at position 200, Mistral-shaped 0.041, perplexity path 0.046)
+# NOTE: these exceed SURVEY 8(c)'s adopted 3e-2. That figure was set before anything was measured; on 32 (40) layers of random-weight fp16
+# arithmetic two VALID evaluations of the reference's own kernels -- the restatement in the reference's lane order and the same sums in another
+# fp32 order -- already sit 0.03-0.05 from the never-rounded forward and up to 0.05 from each other (tools/error_growth.py: its control run),
+# because every fp16 rounding that falls the other way is amplified by the layers behind it. The principled check is therefore the bracket
+# below each comparison: the HIP path may be at most 1.5x (+1e-3) as far from the unrounded double forward as the restatement is (measured
+# after round 5's fix of the truncating accumulate: rms ratio 1.02-1.06, the control's own 1.05).
 BOUND = {"7b": 0.10, "13b": 0.14, "mistral7b": 0.085}
 
 
@@ -46,6 +52,10 @@ def _model(name):
 @pytest.fixture(scope="module")
 def m7b():
     return _model("7b")
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
 
 
 def _rel(a, b):
@@ -79,7 +89,11 @@ def _lockstep(q4, t, m, prompt, steps, f64_steps, bound_vs_restatement, rec=None
         if pos < f64_steps:
             exact = m.forward_f64(toks[pos], pos, cap=f64_steps)
             eg, er = _rel(got, exact), _rel(ref, exact)
+            # the worst of 32000 logits is a noisy statistic (two valid fp32 orders of the reference's own sums differ by as much between
+            # themselves, tools/error_growth.py: control run): 2x on the maximum, 1.5x on the rms over the vocabulary
             assert eg <= 2.0 * er + 1e-3, "pos %d: GPU %g vs restatement %g from the unrounded forward" % (pos, eg, er)
+            rg, rr = _rms(got, exact), _rms(ref, exact)
+            assert rg <= 1.5 * rr + 1e-4, "pos %d: rms distance from the unrounded forward, GPU %g vs restatement %g" % (pos, rg, rr)
             if rec is not None:
                 rec["vs_f64_gpu_max"] = max(rec.get("vs_f64_gpu_max", 0.0), eg)
                 rec["vs_f64_restatement_max"] = max(rec.get("vs_f64_restatement_max", 0.0), er)
@@ -295,6 +309,7 @@ def test_config5_llama2_7b_perplexity_path_64_positions(q4, orc, m7b, observed):
         exact = m.forward_f64(int(toks[i]), i, cap=n64)
         eg, er = _rel(glog[i], exact), _rel(rlog[i], exact)
         assert eg <= 2.0 * er + 1e-3, (i, eg, er)
+        assert _rms(glog[i], exact) <= 1.5 * _rms(rlog[i], exact) + 1e-4, (i, _rms(glog[i], exact), _rms(rlog[i], exact))
     assert _rel(glog, rlog) <= BOUND["7b"]
     rppl = orc.compute_perplexity(toks[1:npos + 1], rlog)
     observed["config5_7b_perplexity"] = {"positions": npos, "perplexity_gpu": float(ppl), "perplexity_restatement": float(rppl),

@@ -128,8 +128,11 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, obser
     # RoPE-paired column order of the fused QKV differs from the plain one -- same terms, another fp32 rounding sequence
     for a, b, pos in zip(outs[0][0], outs[1][0], checkpoints):
         if name == "head128_k5120":
-            d = f16_ulp_diff(a.view(np.float16), b.view(np.float16))
-            assert d.max() <= 2 and (d > 0).mean() <= 0.6, (pos, int(d.max()), float((d > 0).mean()))
+            # a single fp16 value of the residual stream rounding the other way (one ulp of a unit-scale value = 9.8e-4 .. 2e-3) moves every
+            # logit by up to that much: bounded in units of a unit-scale ulp, not of the logit's own (a logit of 1e-5 would read as 1000 ulps)
+            af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
+            err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())
+            assert err <= 4e-3 and (af != bf).mean() <= 0.6, (pos, err, float((af != bf).mean()))
             break                                       # later positions follow their own greedy tokens
         assert np.array_equal(a, b), "logits differ at position %d (fusion 0 vs 1)" % pos
     if name != "head128_k5120":

@@ -122,7 +122,11 @@ def test_linearity_full_size(q4, rng):
     q4.matmul_q4(o2, q4.DevBuf((x * np.float16(2)).astype(np.float16)), dw, K, N)
     q4.synchronize()
     a, b = o1.get(np.float16, N).astype(np.float32), o2.get(np.float16, N).astype(np.float32)
-    assert np.array_equal(a * 2, b)
+    # exact wherever the smaller output is a NORMAL fp16 number: doubling moves the fp32 sum's exponent, not its rounding. An output in the
+    # fp16 denormal range (|y| < 2^-14: fixed spacing 2^-24) rounds its doubled sum on another grid: there one denormal step is allowed
+    normal = np.abs(a) >= 2.0 ** -14
+    assert np.array_equal(a[normal] * 2, b[normal])
+    assert (np.abs(a[~normal] * 2 - b[~normal]) <= 2.0 ** -24).all() and (~normal).sum() < 8
 
 
 class _TailQWeight:

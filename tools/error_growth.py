@@ -42,7 +42,28 @@ for pos in range(npos):
     exact_logits.append(m.forward_f64(toks[pos], pos, cap=npos))
     exact[pos] = d64
     print("cpu position %d done" % pos, file=sys.stderr, flush=True)
+# control: the SAME arithmetic in another valid fp32 order (oracle orc_set_order_variant): how two legitimate evaluations of the reference compare
+oracle.lib().orc_set_order_variant(1)
+ctrl = np.zeros((npos, nl, 2, dim), np.float64)
+for pos in range(npos):
+    m.forward(toks[pos], pos)
+    ctrl[pos] = d16.astype(np.float64)
+oracle.lib().orc_set_order_variant(0)
 m.close()
+
+
+def describe(name, e_a, e_b):
+    """e_a, e_b: errors of two evaluations against the exact forward, [npos, nl, 2, dim]"""
+    print("%s: per half layer -- rms(a) / rms(b), correlation of the two error vectors, rms(a - b) / rms(b), mean signed error a | b" % name)
+    for l in (0, 1, 3, 7, 15, 23, nl - 1):
+        for hh in (0, 1):
+            a, b = e_a[:, l, hh].ravel(), e_b[:, l, hh].ravel()
+            ra, rb = np.sqrt(np.mean(a * a)), np.sqrt(np.mean(b * b))
+            print("   layer %2d %-9s ratio %.4f  corr %.4f  |a-b|/|b| %.4f  mean %+.3e | %+.3e" % (
+                l, "attention" if hh == 0 else "ffn", ra / rb, float(np.mean(a * b) / (ra * rb)), float(np.sqrt(np.mean((a - b) ** 2)) / rb), a.mean(), b.mean()))
+
+
+describe("restatement in another valid fp32 order (a) vs restatement (b)", ctrl - exact, rest - exact)
 
 # ---- GPU: every fusion level, eager, the same token list fed as a prompt ---------------------------------------------
 L = api.lib()
@@ -69,6 +90,8 @@ for level in (3, 1, 0):
     L.q4_set_layer_dump(None)
     tr.close()
     eg, er = gpu - exact, rest - exact
+    describe("fusion level %d: GPU (a) vs restatement (b)" % level, eg, er)
+    describe("fusion level %d: GPU (a) vs restatement in the other order (b)" % level, eg, ctrl - exact)
     rows = []
     for l in range(nl):
         for h in range(2):

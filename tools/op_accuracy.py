@@ -90,11 +90,14 @@ def rope64(v):
     return np.concatenate([a * c - b * sn, a * sn + b * c], axis=1).ravel()
 
 
-dq, dk, dpos = q4.DevBuf(qv), q4.DevBuf(kv), q4.DevBuf(np.array([pos], np.int32))
+kcache = np.zeros((pos + 1, dim), np.float16)      # the kernel rotates the key row INSIDE the cache, at row `pos` (gpu_kernels.h:347-354)
+kcache[pos] = kv
+dq, dk, dpos = q4.DevBuf(qv), q4.DevBuf(kcache), q4.DevBuf(np.array([pos], np.int32))
 q4.RoPERotation(dq, dk, heads, heads, hs, dpos, 0, theta)
 q4.synchronize()
 rq, rk = orc.rope(qv, kv, heads, heads, hs, pos, theta)
 report("rope (q)", dq.get(np.float16, dim), rq, rope64(qv))
+report("rope (k, in the cache)", dk.get(np.float16).reshape(pos + 1, dim)[pos], rk, rope64(kv))
 
 # attention over pos + 1 positions
 kc, vc = h(rng.standard_normal((pos + 1, dim)) * 1.2), h(rng.standard_normal((pos + 1, dim)) * 0.6)
