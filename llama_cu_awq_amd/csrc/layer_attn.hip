@@ -127,7 +127,11 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.nheads = n_heads;
     a.natt = n_heads * s.nsp;
     a.no = dim / (LA_WAVES * la_ocols(s.slots));
-    if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0) {
+    // ... where an o-proj block's share of the weights is small enough to arrive inside the ~4 us of hand-off hops behind the stream (7B, Mistral-7B:
+    // 34 KB per block). Llama-2-13B's 160 blocks pull 85 KB each: held back they end the launch later (tools/sweep_knob.py 13b 15 0,-1: bin 2048
+    // 2.0285 -> 2.1179 ms per token), so they request at entry as before
+    const size_t oproj_block_bytes = ((size_t)g.pw4 * 16 + (size_t)g.pzh * 4 + (size_t)g.sh * 2) * (size_t)dim / a.no;
+    if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0 && (g_ao_hold_pct >= 0 || oproj_block_bytes <= 48 * 1024)) {
         // K and V rows of one position: 2 x kv_dim halves; the stream moves at ~5.9 TB/s (measured, tools/timeline_split.py); 10 ns ticks, Q16
         const double ticks_per_pos = (4.0 * kv_dim) / 5.9e12 * 1e8;
         a.hold_q16 = (unsigned)(ticks_per_pos * 65536.0 * ao_hold_pct(seq_len_bin) / 100.0);
