@@ -96,21 +96,22 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
     constexpr int U = AttShape<LPR, ATT>::U;
     static_assert(U >= 1, "rows in flight");
     const unsigned b = blockIdx.x;
+    unsigned* const sync_words = a.sync;
     Handoff ho = {};
-    ho.error = a.sync + SYNC_ERROR;
+    ho.error = sync_words + SYNC_ERROR;
     // one 8-byte sc1 load: [0] the error word, [1] the epoch. Through a lane-held (opaque) offset on purpose: for a load the
     // compiler can prove wave-uniform it puts s_waitcnt vmcnt(0) + v_readfirstlane right here, and every block of the launch then
     // starts with a second dependent memory round trip (kernel arguments -> this word) before it requests anything else
     // (seen in the ISA; ~0.5 us of the launch). Like this the wait sits at the first use: the polls, or the publishing store.
     unsigned zero_off = 0;
     asm volatile("" : "+v"(zero_off));
-    const u32x2v ee = load_granule(reinterpret_cast<const u32x2v*>(a.sync), zero_off);
+    const u32x2v ee = load_granule(reinterpret_cast<const u32x2v*>(sync_words), zero_off);
     ho.tag = ee[1];          // (the fused QKV launch in front has advanced it: >= 1)
     ho.dead = ee[0];
 #ifdef Q4_PROFILING
     ho.mute = a.mute != 0;
 #endif
-    u32x2v* g_att = reinterpret_cast<u32x2v*>(a.sync + SYNC_GRANULES);
+    u32x2v* g_att = reinterpret_cast<u32x2v*>(sync_words + SYNC_GRANULES);
 #ifdef Q4_PROFILING
     if (a.dbg && threadIdx.x == 0) { a.dbg[b * 4 + 0] = wall_clock64(); a.dbg[b * 4 + 3] = b < a.natt ? 1 : 2; }
     ho.stamp = a.dbg ? a.dbg + b * 4 + 1 : nullptr;
