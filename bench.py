@@ -123,6 +123,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         from llama_cu_awq_amd import replicas
+        # a replica without a GPU of its own fails HERE, loudly, before any rendezvous: one rank falling back to another backend while
+        # its peers initialise RCCL would leave the whole job hanging in the rendezvous
+        if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
+            sys.stderr.write("bench: replica %d of %d has no GPU (this node shows %d): --gpus must not exceed the node's GPUs\n"
+                             % (rank, world, torch.cuda.device_count()))
+            sys.exit(3)
         try:
             torch.cuda.set_device(local_rank)
             dist = replicas.init("nccl", rank, world)   # nccl == RCCL on ROCm; barrier + two scalar reductions only

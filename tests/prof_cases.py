@@ -457,3 +457,36 @@ def test_kv_rings_of_the_split_context_attention_role_are_bit_neutral(q4, model,
     assert outs[0][1] == outs[1][1], "token rings differ"
     for a, b, pos in zip(outs[0][0], outs[1][0], cps):
         assert np.array_equal(a, b), "ring form differs from the register form at position %d" % pos
+
+
+@pytest.mark.parametrize("model,steps", [("head128", 1090), ("tinyllama", 1090)])
+def test_held_back_oproj_weight_requests_are_bit_neutral(q4, model, steps):
+    """Split-context bins (round 5): the o-proj role of the attention -> o-proj launch requests its weights only when the K / V stream is
+    about to end (knob 15: per cent of the stream's estimated duration; -1 = the product's per-bin rule, 0 = at entry). Timing only: logits
+    and token rings must be equal bit for bit whatever the hold, including one far longer than the stream (300 %)."""
+    L = q4.lib()
+    path = _model_file(model)
+    cps = sorted({511, 513, 600, 1023, 1030, steps - 1} & set(range(steps)))
+    outs = {}
+    timeouts = L.q4_handoff_timeouts()
+    try:
+        for hold in (0, -1, 100, 300):
+            L.q4_set_gemv_early(15, hold)
+            t = q4.Transformer(path)
+            t.reset([1, 5, 9])
+            got = []
+            for pos in range(steps):
+                t.run_transformer(pos >= 2)
+                if pos in cps:
+                    q4.synchronize()
+                    got.append(t.logits().view(np.uint16).copy())
+            q4.check(L.q4_handoff_status(t.state))
+            assert L.q4_handoff_timeouts() == timeouts
+            outs[hold] = (got, [int(t.token(i)) for i in range(steps + 1)])
+            t.close()
+    finally:
+        L.q4_set_gemv_early(15, -1)
+    for hold in (-1, 100, 300):
+        assert outs[hold][1] == outs[0][1], "token rings differ (hold %d)" % hold
+        for a, b, pos in zip(outs[0][0], outs[hold][0], cps):
+            assert np.array_equal(a, b), "hold %d: logits differ at position %d" % (hold, pos)
