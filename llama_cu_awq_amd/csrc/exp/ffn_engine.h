@@ -1,7 +1,7 @@
 // exp/ffn_engine.h -- LABORATORY (libllama2_q4_prof.so only; knob 11 = 1..6). the fused gate/up GEMV at K = 4096 as a loader / consumer engine on LDS-DMA (MI355X_MICROARCH.md rows
 // "ldsdma-fill", "nt-weights", "engine-vs-launches"). Same arithmetic as gemv_q4_kernel<MODE_FFN> (rmsnorm_kernel +
 // ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275), bit for bit (tests/prof_cases.py compares the forms). The shipped library does
-// not contain the engine: measured on MI355X (profiles/r04_engine_records.txt) it lands the 47 MB in
+// not contain the engine: measured on MI355X (EXPERIMENTS.md notebook §9.12, profiles/r04_engine_records.txt) it lands the 47 MB in
 // 7.0 us at 7.5 TB/s and still ends AFTER the wave-owned kernel -- 9.76 against 9.51-9.65 us per launch by rocprofv3 in one call, 937
 // against 951 tokens/s as the token loop's gate/up launch -- its two consumer waves per SIMD do not keep up with the dequant (the strips
 // form, four self-loading waves per SIMD, does).

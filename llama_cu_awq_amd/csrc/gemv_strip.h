@@ -1,5 +1,5 @@
 // gemv_strip.h -- "strips": the fused gate/up GEMV (rmsnorm_kernel + ffn_matvec_silu_kernel, gpu_kernels.h:72-105, 256-275) on LDS-DMA rings. Ships
-// for wide matrices (ffn_strip_covers below; DESIGN.md section 3.1b). NO loader wave: one 16-wave block per CU owns a contiguous range of columns;
+// for wide matrices (ffn_strip_covers below; DESIGN.md section 3.2). NO loader wave: one 16-wave block per CU owns a contiguous range of columns;
 // every wave streams its OWN units -- unit u = wave + 16 i of the block's (column, matrix) pairs, 2 KiB each at K = 4096, 2.5 KiB at K = 5120 -- with
 // `buffer_load_dwordx4 ... nt lds` into a private ring of two 1 KiB pieces (lds_dma.h), waits for its oldest piece with vmcnt (a wave's loads return
 // in order), reads it back with ds_read_b128, re-issues and multiplies with the denormal-nibble v_dot2c body of gemv_q4.h. Four waves per SIMD, x staged
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const 
                     } else {
                         cB = __builtin_fmaf(h2f(sc), t, cB);
                     }
-                    asm volatile("" : "+v"(cA), "+v"(cB));                  // the piece's arithmetic stays in front of the next piece's wait (section 3.1b)
+                    asm volatile("" : "+v"(cA), "+v"(cB));                  // the piece's arithmetic stays in front of the next piece's wait
                 }
                 cs[2 * r] = cA;
                 cs[2 * r + 1] = cB;

@@ -5,7 +5,7 @@
 // arithmetic is gemv_f16_kernel's (q4_kernels.hip): per lane and row, for slots s = 0 .. NS - 1: acc = four v_dot2c from zero, sum += acc; wave_sum; one
 // rounding -- so the public matmul and both forms here give the same bits. With NORM the block computes the norm once (the canonical reduction of
 // q4_device.h, rms_apply8: the bits rmsnorm_kernel writes) instead of a launch of its own in front: 16,000 waves redoing it inside gemv_f16_kernel cost
-// more than that launch, 256 blocks do not. Measured (7B, one call): the launch with the norm inside 42.7 / 42.1 / 40.7 us at ring
+// more than that launch (EXPERIMENTS.md notebook §9), 256 blocks do not. Measured (7B, one call): the launch with the norm inside 42.7 / 42.1 / 40.7 us at ring
 // depth 2 / 4 / 8 against 40.2 + 4.7 us for gemv_f16_kernel behind rmsnorm_kernel -- a 262 MB stream sustains 6.2-6.5 TB/s on this chip whatever is in
 // flight --, 969.3 -> 973.0 / 971.8 tokens/s at depth 4 / 8: depth 4 ships.
 // An epilogue policy sees every logit a wave stores (exp/cls_argmax.h: the greedy sampler as this launch's epilogue, measured level and not shipped;

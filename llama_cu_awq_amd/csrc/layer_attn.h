@@ -10,7 +10,7 @@
 // epoch) and runs the dot products. The attention blocks publish with one store instruction each; below bin 512 they never wait
 // (in the split-context bins a head's first chunk block gathers the other chunks' records, which wait for nobody).
 //
-// What the protocol rests on (DESIGN.md section 3.4):
+// What the protocol rests on (DESIGN.md section 3.3):
 //  * forward progress: consumers wait only for producers, producers wait for nobody, and the launcher admits the form only
 //    when the consumers alone cannot fill the stream's CUs (occupancy x CUs > o-proj blocks, attention_oproj_form): a slot
 //    is then always open to a producer; no dispatch order is assumed. Otherwise the layer runs the stand-alone launches.

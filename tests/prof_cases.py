@@ -342,7 +342,7 @@ def test_one_block_and_v_slice_forms_of_the_attention_role(q4, model, steps):
 @pytest.mark.parametrize("name", ["cls4096", "cls5120", "cls4096_ragged"])
 @pytest.mark.parametrize("graphs", [1, 0])
 def test_greedy_sampler_inside_the_classifier_launch(q4, tmp_path, name, graphs):
-    """Knob 12 (measured neutral, not shipped: DESIGN.md section 9 item 19): where the classifier runs as strips (dim 4096 / 5120, a
+    """Knob 12 (measured neutral, not shipped: EXPERIMENTS.md notebook §9.19): where the classifier runs as strips (dim 4096 / 5120, a
     production-size vocabulary) the greedy sampler (argmax_kernel, gpu_kernels.h:448-493) becomes that launch's epilogue: per-block
     candidates, the last block to arrive decides. Every step's token must
     be the argmax of the logits the same launch stored, ties to the lowest index, in the eight-steps-per-replay graphs (the winner's

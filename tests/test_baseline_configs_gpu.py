@@ -155,7 +155,7 @@ def test_mistral_geometry_fused_equals_unfused_bits(q4):
     (gemv_strip_cls.h). At fusion level 1 the rmsnorms are fused into the strips' x staging (the final one into the classifier's), at level 0
     they are launches of their own: the two launch sequences must leave identical logits (same canonical reductions, same rounding
     points), as they do for the wave-owned kernels (test_forward_gpu::test_fused_equals_unfused_bits; level 3 sums an attention output's
-    positions in another fp32 order below bin 512 -- DESIGN.md section 3.2 -- and is held to the restatement by the lockstep tests above.
+    positions in another fp32 order below bin 512 -- DESIGN.md section 3.3 -- and is held to the restatement by the lockstep tests above.
     At K = 5120 -- 13B -- levels 0 and 1 differ with the wave-owned kernels already: level 0's three q / k / v launches and level 1's fused
     one give the shared half slot to different lanes; there the strips are pinned to the wave-owned kernels bit for bit in prof_cases.py)."""
     L = q4.lib()

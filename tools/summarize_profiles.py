@@ -127,7 +127,7 @@ json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent
 
 
 # SQ counters of the gate/up launch run alone (tools/prof_kernel.py 0): VALU instruction count and VALU-busy time per launch -- the
-# evidence behind "the int4 GEMV is VALU-bound" 
+# evidence behind "the int4 GEMV is VALU-bound" (EXPERIMENTS.md notebook §9.13)
 sq = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(src, "pmc_k0_sq", "**", "*counter_collection.csv"), recursive=True):
