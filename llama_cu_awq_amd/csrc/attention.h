@@ -45,7 +45,7 @@ struct AttArgs {
 // of all but the first of them come out of the XCD's L2: the blocks of a head share an XCD), then takes ONE 64-byte slice of
 // the V rows -- 32 of the head's outputs -- with the whole wave: 4 lanes per row, 16 positions per wave instruction, so the
 // P.V pass costs 1/VS of the one-block form's instructions (with two waves per SIMD that pass is an issue-latency chain:
-// 1300-1950 of a head block's 6300-9600 cycles at positions 100 / 220, tools/timeline_attn.py), and publishes that slice. No
+// 1300-1950 of a head block's 6300-9600 cycles at positions 100 / 220, tools/lab/timeline_attn.py), and publishes that slice. No
 // merge and no hand-off between the blocks of a head; the scores, the statistics and the rounding points are the one-block
 // form's, only the fp32 order in which an output sums its positions differs (16 positions per instruction instead of 4).
 // LB: positions the caller guarantees to exist whatever the position word says (bin 256 is entered at position 128): their K
@@ -58,7 +58,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr bool PUB = FUSED != 0;
 #ifdef Q4_PROFILING
-    constexpr bool STAMPS = true;          // profiling build: the fused role is stamped too (tools/timeline_attn.py)
+    constexpr bool STAMPS = true;          // profiling build: the fused role is stamped too (tools/lab/timeline_attn.py)
 #else
     constexpr bool STAMPS = !FUSED;
 #endif
@@ -109,7 +109,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     // alone, hipcc requested q last). Buffer loads bounded at `size` rows: a row past the position is out of range and comes
     // back as zeros WITHOUT a memory request and without a branch; as `if (t < size) load` this compiled to eight exec-masked
     // blocks with an s_waitcnt vmcnt(0) in the middle of them and another one in front of the first dot product: three
-    // dependent round trips, ~2 us (s_memtime stamps, tools/timeline_attn.py). Rows past the position are not requested at all:
+    // dependent round trips, ~2 us (s_memtime stamps, tools/lab/timeline_attn.py). Rows past the position are not requested at all:
     // requesting the whole bin ahead of the position word, to save that dependent latency, was measured 22-31 us per token
     // SLOWER at 7B -- the bytes cost more.
     if constexpr (ULB == 0) qv = *reinterpret_cast<const u32x4*>(a.q + (size_t)h * head_size + subc * 8);
@@ -394,7 +394,7 @@ struct SplitArgs {
     float alpha;
     q4_half* output;
     unsigned* arrive;            // [heads] arrival counters (zero between launches), or null: a second launch merges
-    unsigned long long* dbg;     // profiling build: [(head * chunks + chunk) * NW + wave][8] wall-clock stamps (tools/timeline_split.py)
+    unsigned long long* dbg;     // profiling build: [(head * chunks + chunk) * NW + wave][8] wall-clock stamps (tools/lab/timeline_split.py)
 };
 
 // a live chunk's flash-decode record leaves as 16-byte stores: thread n4 sums the NW wave partials of outputs 4*n4 .. 4*n4+3 (in wave
@@ -440,7 +440,7 @@ constexpr size_t att_split_lds_bytes(int nw, int head_size, int ring) { return (
 struct KvInRegisters { static constexpr unsigned ring_bytes(int) { return 0u; } };
 
 #ifdef Q4_PROFILING
-// per-wave wall-clock stamps (tools/timeline_split.py): [0] entry, [1] position known, [2] q landed, [3] scores done, [4] block maximum known,
+// per-wave wall-clock stamps (tools/lab/timeline_split.py): [0] entry, [1] position known, [2] q landed, [3] scores done, [4] block maximum known,
 // [5] P.V done, [6] record stored, [7] head merged (chunk 0)
 #define SPLIT_STAMP(k) do { if (a.dbg) ts[(k)] = wall_clock64(); } while (0)
 #define SPLIT_STAMP_PIN(k, v) do { if (a.dbg) { asm volatile("" : "+v"(v)); ts[(k)] = wall_clock64(); } } while (0)

@@ -2,7 +2,7 @@
 // split-context attention role with its K / V rows on LDS-DMA rings -- round 5's answer to "a chunk block pulls its 64-128 KB at the ~22 GB/s a CU's
 // registers allow; the strips pull 31-32 GB/s per CU through LDS". Built, bit-identical to the register form (tests/prof_cases.py), measured LEVEL at
 // every ring depth (7B, ms per token inside bin 2048, registers | rings: depth 2 1.1949 | 1.2239, 4 1.1892 | 1.1929, 6 1.1873 | 1.1911, 8 1.1886 |
-// 1.2002; profiles/r05_sweep_ring_d*.txt) -- because the premise was wrong: the stamps (tools/timeline_split.py, profiles/r05_timeline_split_*) show
+// 1.2002; profiles/r05_sweep_ring_d*.txt) -- because the premise was wrong: the stamps (tools/lab/timeline_split.py, profiles/r05_timeline_split_*) show
 // the launch's K / V + o-proj stream already moving at the memory system's ceiling (42 MB in 7.1 us = 5.9 TB/s at position 2042), the rings finish
 // the K rows earlier and the V rows later, and the 4.9 us behind the stream are hand-off hops. Not shipped (EXPERIMENTS.md).
 //

@@ -18,7 +18,7 @@
 // A ring slot = one column quad = 4 columns x 2 matrices x K/8 bytes (16 KiB at K = 4096), contiguous per matrix in HBM
 // (QWeight is column-major per output column: consecutive columns follow each other), so a fill is 16 fully coalesced
 // 1 KiB pieces. Scales and zeros of the block's whole range (7 KiB) are fetched once, by the same loader, in front of the ring.
-// (tools/t_ldsdma.hip pins the instruction's semantics on gfx950: LDS address = M0 + immediate offset + lane * 16, M0 takes the
+// (tools/lab/t_ldsdma.hip pins the instruction's semantics on gfx950: LDS address = M0 + immediate offset + lane * 16, M0 takes the
 // full 160 KiB range.)
 //
 // Synchronisation inside the block (no s_barrier after the entry one: the loader must never wait for a consumer's pace):
@@ -75,7 +75,7 @@ __device__ __forceinline__ void consumer_barrier(unsigned* cnt, unsigned lane, u
 
 // wall-clock stamps (100 MHz, the same counter on every XCD) of one block's loader and of its consumer wave 0, 64 words per
 // block: [0] loader entry, [1] side data issued, [2 + j] fill j known landed, [15] all landed; [16] consumer entry, [17] x staged,
-// [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored (tools/timeline_engine.py).
+// [18 + i] slot i seen landed, [31 + i] slot i multiplied, [44] totals exchanged, [45] outputs stored (tools/lab/timeline_engine.py).
 // A stamp is a global store: it counts in the loader's vmcnt, so stamped runs of LAG = 1 stall on their own stamps.
 #define ENG_STAMP(k) do { if (STAMPS && a.dbg && lane == 0) a.dbg[(size_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
 

@@ -6,7 +6,7 @@
 //          not stage x fill their rings during the x chain, one piece per piece landed; the x chain synchronises through LDS counters
 //          (a wave stalled in vmcnt must not hold a hardware barrier up).
 //   MODE 2: MODE 1 with the dealing order rotated by eight waves: the waves that do not stage x take the longer share.
-//   STAMPS: per-wave wall-clock stamps kept in LDS and written out at the end (tools/timeline_strip.py).
+//   STAMPS: per-wave wall-clock stamps kept in LDS and written out at the end (tools/lab/timeline_strip.py).
 // D = 2, MODE 0 without stamps is the product's kernel (gemv_strip.h, ffn_strip_kernel): tests/prof_cases.py holds every variant to its bits.
 #pragma once
 #include "../gemv_strip.h"
@@ -15,7 +15,7 @@
 namespace q4 {
 
 enum { SF_SS = 0, SF_STAGED = 1, SF_FAIL = 2 };
-// stamps (tools/timeline_strip.py; kept in LDS and written out at the end: a global store would count in vmcnt): [0] wave 0 entry,
+// stamps (tools/lab/timeline_strip.py; kept in LDS and written out at the end: a global store would count in vmcnt): [0] wave 0 entry,
 // [1] its x landed, [2] sum of squares exchanged, [3] x staged, [4 + i] its unit i multiplied, [12] its totals written, [13] outputs
 // stored; [16 + w] wave w entry, [32 + w] wave w's first piece read, [48 + w] wave w's last unit multiplied
 #define SSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
@@ -23,7 +23,7 @@ template <bool NORM, int D, int MODE, bool STAMPS, int TS = 2>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_variant_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
                                                                      const unsigned cbase, const unsigned crem, const GemvArgs a) {
     // the scalars the entry needs come first: built with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of
-    // through a scalar load from the kernel-argument segment (tools/timeline_strip.py: "x landed")
+    // through a scalar load from the kernel-argument segment (tools/lab/timeline_strip.py: "x landed")
     static_assert(D == 2 || D == 4 || D == 8, "ring entries of a unit's pieces are compile-time constants");
     static_assert(TS == 2 || (TS == 3 && MODE == 0 && D <= 4), "K = 5120: the plain form, 12 pieces per four units a multiple of the ring");
     constexpr bool PACED = MODE >= 1;

@@ -23,7 +23,7 @@ static bool lab_ffn_covers(const GemvArgs& a) {
     if (g_ablate) return pick_slots(a.nslots) == 2 && a.rms_w != nullptr && g_ablate >= 1 && g_ablate <= 4;   // ablations of the 7B gate/up kernel
     if (ffn_engine_covers(a)) return true;
     if (strips_variant_form()) return ffn_strip_shape(a);                       // a strips variant wherever the shape is covered
-    return a.dbg != nullptr && !strip_k5120(a) && ffn_strip_covers(a);          // tools/timeline_strip.py: the product's form, stamped
+    return a.dbg != nullptr && !strip_k5120(a) && ffn_strip_covers(a);          // tools/lab/timeline_strip.py: the product's form, stamped
 }
 template <bool NORM, bool STAMPS>
 static int launch_strip_setting(const GemvArgs& a) {

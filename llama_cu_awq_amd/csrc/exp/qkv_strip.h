@@ -14,7 +14,7 @@
 //   * a column's half piece goes to the lower half of the wave for even pairs and to the upper half for odd ones: the lanes and operations of
 //     gemv_q4.h's shared half slot (there: pair 2 wg below, pair 2 wg + 1 above).
 // Same arithmetic in the same order as gemv_q4_kernel<MODE_QKV, 3, 4, NORM, 0, 1, true>: bit for bit (tests/prof_cases.py) -- and SLOWER: 9.65 against
-// 8.97 us per launch by HIP events inside the eager 13B network (tools/qkv_strip_time.py), 565.1 -> 558.0 and 561.0 -> 551.8 tokens/s at 13B -n 256
+// 8.97 us per launch by HIP events inside the eager 13B network (tools/lab/qkv_strip_time.py), 565.1 -> 558.0 and 561.0 -> 551.8 tokens/s at 13B -n 256
 // (knob 11 = 16 against 0 while the form was the product's choice, one process each). Strips stream 160 KB per CU at the rate the 13B down
 // projection's strips reach (144 KB in 8.4 us); that beat a K-split grid of 2.5 blocks per CU (10.5 us) and does not beat this launch's 3.75 blocks
 // per CU. Profiling build only, knob 11 = 8 (EXPERIMENTS.md notebook §9.20).

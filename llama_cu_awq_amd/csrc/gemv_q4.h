@@ -16,7 +16,7 @@
 //  * dequant without converts, subtracts or magic exponents -- the kernel is VALU-bound if written naively (measured:
 //    v_and_or, v_dot2c, v_pk_*, v_cvt_* issue at half rate, ~1.8 ns per wave instruction per SIMD; plain VOP2 integer
 //    ops at full rate): a nibble left in place IS an fp16 denormal, (w & 0x000F000F) = the half2 (q_i, q_{i+4}) * 2^-24,
-//    and v_dot2c_f32_f16 multiplies denormal inputs exactly (verified on gfx950, tools/t_denorm.hip). The odd nibbles
+//    and v_dot2c_f32_f16 multiplies denormal inputs exactly (verified on gfx950, tools/lab/t_denorm.hip). The odd nibbles
 //    sit 4 bits higher (16 q * 2^-24). Two fp32 accumulators, acc_e and acc_o, then
 //        sum_k q x = 2^20 (16 acc_e + acc_o),      sum_k (q - z) x = that - z * (sum of the 32 x)
 //    with the x-only sum computed once per block at staging and the 2^20 applied once per column at the end (all
@@ -78,7 +78,7 @@ struct GemvArgs {
 // never match. Consumers put their weight loads in flight first, then poll with uncached (sc1) loads, bounded, with s_sleep.
 // Polls must stay off shared lines: an uncached poll lands on the memory channel of its address, and since a wave's loads
 // return in order, 160 blocks polling two shared cache lines stalled every weight stream of the launch (the later QKV
-// blocks ended 4-10 us late, tools/timeline_block.py). Here a line is polled by at most a handful of blocks.
+// blocks ended 4-10 us late, tools/lab/timeline_block.py). Here a line is polled by at most a handful of blocks.
 // (MI355X_MICROARCH.md: "handoff-1to1 ... data-tagged granules", R2.) ROLE_NONE compiles to the stand-alone kernel.
 constexpr int ROLE_NONE = 0, ROLE_CONSUMER = 2;
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
@@ -143,7 +143,7 @@ __device__ __forceinline__ float reduce4_rows(float v0, float v1, float v2, floa
 }
 
 // The accumulate that does not round to nearest. v_dot2c_f32_f16 (D = a.x * b.x + a.y * b.y + D) aligns its three addends and TRUNCATES toward minus
-// infinity: on this kernel family's operands (denormal nibbles x fp16 inputs + a running sum) tools/t_dot2_round.hip measures a mean error of -0.3 ..
+// infinity: on this kernel family's operands (denormal nibbles x fp16 inputs + a running sum) tools/lab/t_dot2_round.hip measures a mean error of -0.3 ..
 // -0.4 fp32 ulp per instruction where round-to-nearest has 0. 2048 such instructions per output add up to a signed error of about -4e-6 per GEMV output
 // (-2e-5 for the down projection's inputs, tools/bias_probe.py), the same for every output: a coherent offset that the residual stream accumulates
 // (-4.6e-5 per layer) and that weights with a non-zero column mean turn into 7 % more distance from the exact forward than the reference's own
@@ -309,7 +309,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     // Buffer loads: descriptor per tensor (SGPRs), wave-uniform column byte offset in soffset (SGPR), the lane's
     // offset inside the column in voffset (one VGPR per slot, shared by every column and matrix) -> no per-load
     // address arithmetic on the VALU. aux = 2 is the non-temporal hint (weights are read once per token).
-    // measured on MI355X (tools/sweep_gemv.py): for K <= 8192 staging FIRST wins (QKV 8.1 -> 7.4 us, gate 6.3 -> 5.7 us):
+    // measured on MI355X (tools/lab/sweep_gemv.py): for K <= 8192 staging FIRST wins (QKV 8.1 -> 7.4 us, gate 6.3 -> 5.7 us):
     // the x chain is short when no weight request is queued ahead of it; for the long-K down projection
     // (6-7 slots, 1 wave per SIMD) half of the loads in front of the staging hides it better (7.5 -> 7.2 us)
     // ABL == 5 is not an ablation but the "all loads first" order: when the grid is about one block per CU (o-proj:
@@ -618,7 +618,7 @@ static int launch_one(const GemvArgs& a0, int waves) {
     GemvArgs a = a0;
     if (a.early > 0 && a.early < 256) {
         // early birds hold back until the launch's x loads are queued: that takes longer the more waves share a CU
-        // (measured, tools/sweep_early.py: <= 12 waves per CU none, 15 -> 4 x 128 cycles, >= 21 -> 8 x 128)
+        // (measured, tools/lab/sweep_early.py: <= 12 waves per CU none, 15 -> 4 x 128 cycles, >= 21 -> 8 x 128)
         const int waves_per_cu = (int)((size_t)grid.x * grid.y * waves / (size_t)cu_count());
         a.early |= (waves_per_cu <= 12 ? 0 : waves_per_cu <= 16 ? 4 : 8) << 8;
     }

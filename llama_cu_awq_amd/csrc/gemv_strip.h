@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_strip_pair_kernel(const 
 
 // Shapes: K = 4096 (two 1 KiB pieces per column), 16 .. 56 columns per CU, on a stream that may use every CU (the blocks do not wait for
 // each other: on a CU-masked stream the form would be correct, only slow). Strips run from STRIP_MIN_COLS columns per CU on, where they measure
-// faster than the wave-owned kernel (tools/sweep_strips.py, per launch in a graph, wave-owned | strips: 16 columns per CU 4.92 | 5.39 us, 20: 5.88 | 5.92,
+// faster than the wave-owned kernel (tools/lab/sweep_strips.py, per launch in a graph, wave-owned | strips: 16 columns per CU 4.92 | 5.39 us, 20: 5.88 | 5.92,
 // 24: 6.25 | 6.46, 28: 7.12 | 6.98, 32: 7.78 | 7.75, 36: 8.57 | 8.23, 40: 9.15 | 9.01, 43 (Llama-2-7B): 10.12 | 9.69, 46: 10.08 | 9.72; the Mistral /
 // Llama-3 hidden size 14336: 12.4 -> 11.45 us, 885 -> 902 tokens/s on the Mistral-7B geometry; Llama-2-7B -n 256 982.7 -> 990.8 tokens/s against a build
 // with the threshold at 49). g_gemv_form (q4_internal.h) is GEMV_PRODUCT in the shipped library; the profiling library's knob 11 sets the others.

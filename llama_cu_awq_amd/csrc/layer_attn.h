@@ -48,7 +48,7 @@ struct AttOprojArgs {
 // 7 / 8 / 9 (laboratory, profiling library only): the split-context forms 2 / 3 / 4 with their K / V rows on LDS-DMA rings (exp/attention_ring.h; same bits,
 // measured level).
 #ifndef Q4_ATT_RING
-#define Q4_ATT_RING 4                // 1 KiB pieces per wave of the ring forms (tools/build_ring_variants.sh builds other depths for the A/B)
+#define Q4_ATT_RING 4                // 1 KiB pieces per wave of the ring forms (tools/lab/build_ring_variants.sh builds other depths for the A/B)
 #endif
 // block LDS of the launch: the default 64 KiB without an opt-in; ring depths of 8 pieces and more (A/B builds) opt in where they are first asked for
 constexpr size_t AO_LDS_MAX = Q4_ATT_RING > 7 ? 160 * 1024 : 64 * 1024;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
         const unsigned j = b - a.natt;
         if constexpr (att_is_split(ATT)) {
             // The chunk blocks' K / V rows (16 KB per position at 7B: 33.5 MB at 2048) move at the memory system's ceiling (5.6-5.9 TB/s,
-            // tools/timeline_split.py); this role's weights (8.7 MB) are not needed before the heads are merged, 4-5 us after that stream
+            // tools/lab/timeline_split.py); this role's weights (8.7 MB) are not needed before the heads are merged, 4-5 us after that stream
             // ends. Requested at entry they are a fifth of the stream's bytes, in front of rows the whole launch waits for; so they are
             // requested when the stream is about to end: a time per context position priced by the host from the rows' bytes.
             if (a.hold_q16 != 0u) {

@@ -15,7 +15,7 @@ int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention
 int g_ao_vslice = 1;  // below the split-context bins: head_size / 32 attention blocks per head, one 64-byte V slice each (0: one block)
 int g_att_ring = 0;   // profiling knob 14: the split-context attention role takes its K / V rows on LDS-DMA rings (same bits, same speed: DESIGN.md)
 // split-context bins: the o-proj role requests its weights after this share of the K / V stream's estimated duration (0: at entry). -1 = the measured
-// optimum per bin (tools/sweep_attn_hold.py, 7B, ms per token inside the bin, hold 0 / 100 / 140 / 180 %: bin 512 1.0933 / 1.0777 / 1.0710 / 1.0807,
+// optimum per bin (tools/lab/sweep_attn_hold.py, 7B, ms per token inside the bin, hold 0 / 100 / 140 / 180 %: bin 512 1.0933 / 1.0777 / 1.0710 / 1.0807,
 // bin 1024 1.1229 / 1.1120 / 1.1255 / 1.1334, bin 2048 1.1925 / 1.1812 / 1.1979 / 1.2147)
 int g_ao_hold_pct = -1;
 static int ao_hold_pct(int seq_len_bin) { return g_ao_hold_pct >= 0 ? g_ao_hold_pct : seq_len_bin <= 512 ? 140 : 100; }
@@ -59,7 +59,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     s.launch = head_size == 64 ? launch_attention_oproj_h64 : head_size == 128 ? launch_attention_oproj_h128 :
                head_size == 256 ? launch_attention_oproj_h256 : nullptr;
     if (!s.launch || !(kv_dim > 0 && dim % kv_dim == 0 && (dim % (LA_WAVES * la_ocols(s.slots))) == 0)) return s;
-    // eight chunks per head = one attention block per CU at 32 heads (measured per bin, tools/sweep_attn_bins.py), 64..256 positions
+    // eight chunks per head = one attention block per CU at 32 heads (measured per bin, tools/lab/sweep_attn_bins.py), 64..256 positions
     const int auto_chunk = seq_len_bin <= 512 ? 64 : seq_len_bin <= 1024 ? 128 : 256;
     const int chunk = split_chunk ? split_chunk : auto_chunk;
     if (chunk != 64 && chunk != 128 && chunk != 256) return s;
@@ -128,11 +128,11 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.natt = n_heads * s.nsp;
     a.no = dim / (LA_WAVES * la_ocols(s.slots));
     // ... where an o-proj block's share of the weights is small enough to arrive inside the ~4 us of hand-off hops behind the stream (7B, Mistral-7B:
-    // 34 KB per block). Llama-2-13B's 160 blocks pull 85 KB each: held back they end the launch later (tools/sweep_knob.py 13b 15 0,-1: bin 2048
+    // 34 KB per block). Llama-2-13B's 160 blocks pull 85 KB each: held back they end the launch later (tools/lab/sweep_knob.py 13b 15 0,-1: bin 2048
     // 2.0285 -> 2.1179 ms per token), so they request at entry as before
     const size_t oproj_block_bytes = ((size_t)g.pw4 * 16 + (size_t)g.pzh * 4 + (size_t)g.sh * 2) * (size_t)dim / a.no;
     if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0 && (g_ao_hold_pct >= 0 || oproj_block_bytes <= 48 * 1024)) {
-        // K and V rows of one position: 2 x kv_dim halves; the stream moves at ~5.9 TB/s (measured, tools/timeline_split.py); 10 ns ticks, Q16
+        // K and V rows of one position: 2 x kv_dim halves; the stream moves at ~5.9 TB/s (measured, tools/lab/timeline_split.py); 10 ns ticks, Q16
         const double ticks_per_pos = (4.0 * kv_dim) / 5.9e12 * 1e8;
         a.hold_q16 = (unsigned)(ticks_per_pos * 65536.0 * ao_hold_pct(seq_len_bin) / 100.0);
     }

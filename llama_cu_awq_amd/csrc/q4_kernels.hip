@@ -20,7 +20,7 @@ int g_half_tail = 1;
 int g_att_chunk = 0;         // positions per split-attention block (64 / 128 / 256), or 0 = measured per bin: the fused launch takes eight
                              // chunks per head (64 in bin 512, 128 in bin 1024, 256 above), the stand-alone kernels 128 up to bin 1024
 int g_att_8wave = 0;         // head 128, bins 256 / 512: 8 waves x 8 loads in flight (1, the fused launch's shape) or 16 waves x 4
-                            // (0: 8 us per token faster stand-alone, tools/sweep_block2.py)
+                            // (0: 8 us per token faster stand-alone, tools/lab/sweep_block2.py)
 int g_att_split_min = 512;   // smallest sequence-length bin that uses the split-context kernels
 unsigned long long* g_dbg = nullptr;
 // early = 4: exactly the first block on each CU (measured: partial blocks or a second block lose the gain). The

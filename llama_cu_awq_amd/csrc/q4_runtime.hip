@@ -475,7 +475,7 @@ TransformerWeights* q4_transformer_weights(Transformer* t) { return &t->weights;
 // run_llama_network, llama2_q4.cu:286-340
 #define Q4_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
-// measurement knob (tools/breakdown.py): leave out a class of launches to read its marginal cost inside the token
+// measurement knob (tools/lab/breakdown.py): leave out a class of launches to read its marginal cost inside the token
 // graph. Results are garbage with any bit set; never set by the product path.
 #ifdef Q4_PROFILING
 static int g_skip = 0;

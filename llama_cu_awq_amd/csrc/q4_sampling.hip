@@ -21,7 +21,7 @@ using namespace q4;
 namespace {
 
 // profiling build: wall-clock stamps (100 MHz) of the kernel's phases, written by thread 0 into the sampler's `indices` scratch
-// (which nothing else uses) as 64-bit words: tools/sampler_kernel_time.py prints them
+// (which nothing else uses) as 64-bit words: tools/lab/sampler_kernel_time.py prints them
 #ifdef Q4_PROFILING
 #define SMP_STAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(indices)[k] = wall_clock64(); } while (0)
 #else
@@ -295,7 +295,7 @@ __device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot
 }
 
 // Vocabularies of up to 32 x 1024 entries, a multiple of 8: the softmax's elementwise work (a division, an exponential) and its
-// sum spread over SMX_B = 16 CUs -- on one CU it is 17 us of the sampling launch (tools/sampler_kernel_time.py stamps) -- in the
+// sum spread over SMX_B = 16 CUs -- on one CU it is 17 us of the sampling launch (tools/lab/sampler_kernel_time.py stamps) -- in the
 // SAME arithmetic order as softmax_phase, whose canonical sum is: thread t of 1024 adds its elements t + 1024 k for ascending k, a
 // wave tree over each 64 threads, a 16-lane DPP tree over the 16 wave totals. Block b of this launch is "wave b": its lanes are the
 // virtual threads 64 b .. 64 b + 63. Every block finds the global maximum by itself (the whole vocabulary is 64 KB of L2 hits: no

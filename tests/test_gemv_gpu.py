@@ -178,7 +178,7 @@ def test_strips_side_data_stays_inside_tensors_that_end_with_their_allocation(q4
 
 
 def test_int4_gemv_has_no_systematic_error(q4, orc, rng):
-    """v_dot2c_f32_f16 truncates its accumulate toward minus infinity (tools/t_dot2_round.hip): left alone, every output of an int4 GEMV
+    """v_dot2c_f32_f16 truncates its accumulate toward minus infinity (tools/lab/t_dot2_round.hip): left alone, every output of an int4 GEMV
     carries the same small negative error -- round 4's kernels: -2.0e-5 +- 8e-7 on this case, the restatement -4e-7 -- which the residual
     stream accumulates layer after layer (tools/error_growth.py). The kernels stage odd uint4 units negated so that even and odd lanes err
     in opposite directions (csrc/gemv_q4.h, q4_stage_sign_bits): the mean signed error over 8 x 4096 outputs of a unit-scale down
