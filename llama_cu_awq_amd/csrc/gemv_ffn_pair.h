@@ -1,0 +1,437 @@
+// gemv_ffn_pair.h -- the FFN half of a layer as ONE launch (fusion level 4): rmsnorm + gate/up + SiLU (rmsnorm_kernel + ffn_matvec_silu_kernel,
+// gpu_kernels.h:72-105, 256-275; llama2_q4.cu:326-329) and the down projection with its residual add (mat_vec_kernel_int4, gpu_kernels.h:213-240;
+// llama2_q4.cu:332). One 16-wave block per CU, all blocks resident (a CU holds one: 146 KiB of LDS):
+//   phase 1  the block's share of gate/up columns exactly as gemv_strip.h streams them (every wave its own (column, matrix) units on a private ring
+//            of two 1 KiB LDS-DMA pieces). A block owns whole column PAIRS, so that its slice of hb leaves as 8-byte granules {two halves, tag}.
+//   seam     a wave's stream does not end with its last gate/up piece: it continues with the block's share of the DOWN projection's weights -- the
+//            16 output columns of this CU are one contiguous run of the tensor, 86 KiB at Llama-2-7B -- which land in LDS the gate/up phase does not
+//            use and stay there: the down stream runs under the seam instead of behind a launch boundary. Wave 0 publishes the block's slice of hb
+//            (one sc1 store per lane; also the plain hb vector, RunState::hb); waves 1..15 gather the whole vector -- every thread its own one or two
+//            8-half chunks, re-reading only what does not carry the launch's tag yet, one more down piece between two passes -- and stage it in the
+//            K-split kernel's permuted layout over the dead gate/up rings.
+//   phase 2  the down projection's dot products on weights that are already in LDS: units (column, k-part), lanes, slots and the part-0-then-part-1
+//            sum of gemv_q4_kernel<MODE_PLAIN, 3, 4, false, 0, 2> (= down_strip_kernel<3, false>), residual add, one rounding.
+// Same arithmetic in the same order as the two launches it replaces: bit for bit (tests/prof_cases.py, tests/test_forward_gpu.py).
+// Protocol (as layer_attn.h): the tag is the model's epoch word, advanced by the PRECEDING fused QKV launch; every block is producer first and
+// consumer second, producers wait for nobody, so the launch cannot wedge while all blocks are resident (grid = CUs of the device, the stream unmasked:
+// ffn_pair_covers); every wait is bounded and a run-out sets the model's sticky error word (q4_handoff_status: one clean retry at fusion level 1).
+#pragma once
+#include "gemv_strip.h"
+
+namespace q4 {
+
+struct FfnPairArgs {
+    GemvMat d;                 // the down projection's tensors
+    q4_half* xio;              // residual stream: the launch's rmsnorm input, and x += down at its end (llama2_q4.cu:332, accum)
+    const unsigned* sync;      // hand-off words of the model: [SYNC_ERROR], [SYNC_EPOCH] (one aligned 8-byte word)
+    unsigned* error;           // = sync + SYNC_ERROR
+    u32x2v* gran;              // hidden / 2 granules {hb[2 g], hb[2 g + 1], tag}
+    int Kd, Nd, pw4, pzh, sh, ku;   // down projection: K = hidden, N = dim, packed geometry, uint4 units per k-part (gemv_q4.h, KS = 2)
+    unsigned dbase, drem;      // its output columns per block
+    unsigned pre;              // gather mode: bit 0 = the first pass with plain loads, bit 1 = ... once the wave's own down pieces have landed
+    int mute;                  // profiling build: the blocks do not publish (a real time-out, tests/prof_cases.py)
+    unsigned long long* dbg;   // profiling build: [block][64] wall-clock stamps
+};
+
+constexpr int FP_ROWS = 6;             // 64-unit rows of the staged hb vector: hidden <= 12288
+constexpr int FP_NC2MAX = 16;          // down projection columns per block
+struct FfnPairLds {
+    using G = StripLds<2, 2>;
+    static constexpr unsigned XS2 = 0;                              // [6][4][64] x 16 B permuted hb -- over the gate/up rings, dead behind barrier A
+    static constexpr unsigned SX2 = XS2 + FP_ROWS * 4096u;          // [6][64] -(sum of the 32 inputs) * 2^-20
+    static_assert(SX2 + FP_ROWS * 256u <= G::SIDE_S, "the staged hb vector fits in the gate/up rings");
+    static constexpr unsigned TOT2 = G::BYTES;                      // [16][2] k-part totals
+    static constexpr unsigned DSIDE_S = TOT2 + 256u;                // 3 KiB: 16 columns x <= 96 groups x 2 B
+    static constexpr unsigned DSIDE_Z = DSIDE_S + 3072u;            // 1 KiB: 16 columns x <= 16 words x 4 B
+    static constexpr unsigned DW = DSIDE_Z + 1024u;                 // the block's columns of the down projection, as they lie in the tensor
+    static constexpr unsigned DW_BYTES = 88u * 1024u;
+    static constexpr unsigned BYTES = DW + DW_BYTES;
+};
+static_assert(FfnPairLds::BYTES <= 160 * 1024, "one block per CU");
+static_assert(FfnPairLds::DW % 16 == 0 && FfnPairLds::TOT2 % 16 == 0, "alignment");
+constexpr unsigned FP_POLL_LIMIT = 1u << 18;    // gather passes without a down piece in between (each a memory round trip + s_sleep): ~0.3 s, then give up
+
+#define FPSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
+template <bool NORM, bool STAMPS>
+__global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
+                                                                    const unsigned pbase, const unsigned prem, const GemvArgs a, const FfnPairArgs p) {
+    constexpr int TS = 2, D = 2;
+    constexpr unsigned CB = 2048u, G = 32u, ZW = 4u;
+    constexpr int NSTAGE = 8;
+    using L = StripLds<D, TS>;
+    using P = FfnPairLds;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned bp = blockIdx.x * pbase + (blockIdx.x < prem ? blockIdx.x : prem);
+    const unsigned c0 = 2u * bp;                                   // first gate/up column of this block (even)
+    const int nc = 2 * (int)(pbase + (blockIdx.x < prem ? 1u : 0u));
+    const unsigned c0d = blockIdx.x * p.dbase + (blockIdx.x < p.drem ? blockIdx.x : p.drem);   // first down column
+    const int nc2 = (int)(p.dbase + (blockIdx.x < p.drem ? 1u : 0u));
+    const int mat = wave & 1;
+    const int nu = (2 * nc - wave + 15) >> 4;
+    const int npieces = TS * nu;
+    const unsigned voff = lane * 16u;
+    const bool stager = wave < NSTAGE;
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + L::STAMP);
+    if (STAMPS && wave == 0) { st[lane] = 0ull; FPSTAMP(0); }     // [0] entry, [1..3] x chain, [4] barrier A, [5] published, [6..7] wave 1 first pass / complete, [9] barrier B, [10] dots, [11] stored,
+                                                                  // [12] passes; per wave: [16 + w] gathered, [32 + w] gate/up done, [48 + w] down pieces landed
+
+    // ---- entry, as ffn_strip_kernel: x first, then the hand-off word, the side data of both phases, then the ring
+    u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
+    if (stager) {
+        const u32x4* px = arg_x + tid;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
+        if (NORM) {
+            const u32x4* pw = arg_rms + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
+        }
+    }
+    u32x2v ee = {0u, 0u};                                // [0] the error word, [1] the epoch = this launch's tag (advanced by the fused QKV launch in front: >= 1)
+    {
+        const unsigned* pe = p.sync;
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(ee) : "v"(pe) : "memory");
+    }
+    constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);      // 5 side pieces per gate/up matrix
+    if (wave < 2 * NSIDE) {
+        const int m = wave >= NSIDE, q = wave - NSIDE * m;
+        if (q < (int)L::NS_S) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[m].s, c0 * (G * 2u), (unsigned)(a.N * a.sh * 2));
+            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[m].z, c0 * (ZW * 4u), (unsigned)(a.N * a.pzh * 4));
+            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (q - (int)L::NS_S) * 1024u, voff + (unsigned)(q - (int)L::NS_S) * 1024u, rz, 0u);
+        }
+    } else if (wave < 2 * NSIDE + 4) {                   // the down projection's scales (three pieces) and zeros (one) of this block's columns
+        const int q = wave - 2 * NSIDE;
+        if (q < 3) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_from(p.d.s, c0d * (unsigned)p.sh * 2u, (unsigned)(p.Nd * p.sh * 2));
+            dma_piece_default(P::DSIDE_S + (unsigned)q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rz = rsrc_from(p.d.z, c0d * (unsigned)p.pzh * 4u, (unsigned)(p.Nd * p.pzh * 4));
+            dma_piece_default(P::DSIDE_Z, voff, rz, 0u);
+        }
+    }
+    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
+    const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
+    const unsigned soff0 = (c0 + ((unsigned)wave >> 1)) * CB;
+    auto issue2 = [&](int i, int ks) {
+        const unsigned dst = ring + (unsigned)((TS * i + ks) & (D - 1)) * 1024u, so = soff0 + (unsigned)i * (8u * CB) + (unsigned)ks * 1024u;
+        dma_piece(dst, voff, rw, so);
+    };
+    // the stream's continuation: the down projection's weights of this block -- its output columns are ONE contiguous run of the tensor, which lands in
+    // LDS as it lies in memory. A wave requests the pieces of its OWN phase-2 units (column wave / 2 + 8 i, k-part wave % 2: three pieces of 64, 64 and
+    // ku - 128 uint4), so that its own vmcnt tells it when they have landed: no block barrier between the stream and the unpacking below.
+    const unsigned colbytes2 = (unsigned)p.pw4 * 16u, share = (unsigned)nc2 * colbytes2;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.d.w) + (size_t)c0d * colbytes2), 0, (int)share, 0x00020000);
+    const int nu2 = (2 * nc2 - wave + 15) >> 4;                       // this wave's units of phase 2 (<= 2)
+    const unsigned ku = (unsigned)p.ku, ubase = (unsigned)(wave & 1) * ku;
+    const unsigned uend = ubase + ku < (unsigned)p.pw4 ? ubase + ku : (unsigned)p.pw4;
+    const int ndp = 3 * nu2;
+    auto issue_down = [&](int r) {                                     // piece r = 3 i + ks
+        const unsigned i = r >= 3 ? 1u : 0u, ks = (unsigned)r - 3u * i;
+        const unsigned lc = ((unsigned)wave >> 1) + 8u * i;
+        const unsigned first = lc * (unsigned)p.pw4 + ubase + 64u * ks;  // in uint4 units from the block's first column
+        if (64u * ks + lane < ku && ubase + 64u * ks + lane < uend) dma_piece(P::DW + first * 16u, voff, rd, first * 16u);
+    };
+    const int nstream = npieces + ndp;
+#pragma unroll
+    for (int k = 0; k < D; k++)
+        if (k < npieces) issue2(k / TS, k % TS);
+
+    // ---- x chain (ffn_strip_kernel's)
+    u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
+    float* sx = reinterpret_cast<float*>(smem + L::SX);
+    float* part = reinterpret_cast<float*>(smem + L::PART);
+    float* tot = reinterpret_cast<float*>(smem + L::TOT);
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(xraw), "+v"(wraw), "+v"(ee) : "n"(D) : "memory");   // all but the weight pieces (every wave has units: ffn_pair_covers)
+    if (wave == 0) FPSTAMP(1);
+    if (NORM) {
+        if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;
+        block_barrier_lds();
+        if (wave == 0) FPSTAMP(2);
+    }
+    if (stager) {
+        float ss = 1.f;
+        if (NORM) ss = rms_scale_from_partials<TS * 256>(part, TS * 256, a.K);
+        u32x4 v = xraw;
+        const unsigned sgn = q4_stage_sign_bits(tid);
+        if (NORM) v = rms_apply8(v, wraw, q4_signed_scale(ss, sgn));
+        else v = q4_signed_x(v, sgn);
+        const u32x4 pv = permute_x8(v);
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        float cb = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+        cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+        const unsigned j = tid >> 2, d = tid & 3u;
+        xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+        if (d == 0) sx[j] = cb * -9.5367431640625e-07f;
+    }
+    block_barrier_lds();                               // x staged; side data landed
+    if (wave == 0) FPSTAMP(3);
+    {
+        u32x4 X[TS][4];
+        float corr[TS];
+#pragma unroll
+        for (int ks = 0; ks < TS; ks++) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) X[ks][d] = xs[((ks * 4 + d) << 6) + lane];
+            corr[ks] = sx[ks * 64 + lane];
+        }
+        const unsigned char* wbase = smem + ring + lane * 16u;
+        const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wave >> 1) * G + (lane >> 2)) * 2u;
+        const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wave >> 1) * ZW + (lane >> 5)) * 4u;
+        const unsigned zsh = ((lane >> 2) & 7u) * 4u;
+
+        for (int g4 = 0; g4 * 4 < nu; g4++) {
+            float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = g4 * 4 + r;
+                if (i < nu) {
+                    float c = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < TS; ks++) {
+                        const int j = TS * i + ks;
+                        const int e = (TS * r + ks) & (D - 1);
+                        if (j + 1 < nstream) wait_vmcnt<D - 1>(); else wait_vmcnt<0>();     // piece j has landed
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
+                        const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (8u * G * 2u) + ks * 32);
+                        const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (8u * ZW * 4u) + ks * 8);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
+                        if (j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
+                        else if (j + D < nstream) issue_down(j + D - npieces);                // ... and behind the last gate/up piece the stream goes on
+                        float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            const unsigned ww = w[d];
+                            const unsigned tt = ww >> 8;
+                            acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[ks][d][0]), acc_e, false);
+                            acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[ks][d][1]), acc_o, false);
+                            acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[ks][d][2]), acc_e, false);
+                            acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[ks][d][3]), acc_o, false);
+                        }
+                        const float zf = (float)((zw >> zsh) & 0xFu);
+                        float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                        t = __builtin_fmaf(zf, corr[ks], t);
+                        c = __builtin_fmaf(h2f(sc), t, c);
+                    }
+                    cs[r] = c;
+                }
+            }
+            const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
+            const int row = lane >> 4;
+            if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wave + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
+        }
+    }
+    FPSTAMP(32 + wave);
+    block_barrier_lds();                               // barrier A: the block's gate/up totals are in LDS, its rings are dead
+    int rnext = ndp < D ? ndp : D;                     // down pieces this wave has requested so far
+
+    // ---- the seam
+    const unsigned tag = ee[1], dead = ee[0];
+    u32x4 ha = {0u, 0u, 0u, 0u}, hb2 = {0u, 0u, 0u, 0u};    // this thread's chunks of hb (8 halves each)
+    const unsigned gt = tid - 64u;                          // gather thread (waves 1 .. 15): chunks gt and gt + 960
+    const unsigned nch2 = (unsigned)p.Kd >> 3;
+    const unsigned tail = ku - 128u;
+    // phase 2's weights, unpacked while the wave waits for the vector: [unit][slot][dword] x {n0 n4, n1 n5 << 4, n2 n6, n3 n7 << 4} as fp16 denormal pairs
+    // (the last piece of the second unit stays packed: 128 registers per lane at sixteen waves per CU)
+    unsigned pm[2][3][16];
+    u32x4 wlast = {0u, 0u, 0u, 0u};
+    auto unpack = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const unsigned lc = ((unsigned)wave >> 1) + 8u * (unsigned)i;
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const unsigned unit = ubase + 64u * (unsigned)ks + lane;
+                const unsigned uj = unit < uend ? unit : uend - 1u;
+                u32x4 w = {0u, 0u, 0u, 0u};
+                if (i < nu2) w = *reinterpret_cast<const u32x4*>(smem + P::DW + (lc * (unsigned)p.pw4 + uj) * 16u);
+                if (i == 1 && ks == 2) { wlast = w; continue; }
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const unsigned ww = w[d], tt = ww >> 8;
+                    pm[i][ks][4 * d + 0] = ww & 0x000F000Fu;
+                    pm[i][ks][4 * d + 1] = ww & 0x00F000F0u;
+                    pm[i][ks][4 * d + 2] = tt & 0x000F000Fu;
+                    pm[i][ks][4 * d + 3] = tt & 0x00F000F0u;
+                }
+            }
+        }
+    };
+    if (wave == 0) {
+        FPSTAMP(4);
+        if ((int)lane * 2 < nc) {      // SiLU(gate) * up of one column pair (gpu_kernels.h:271-272), the epilogue of ffn_strip_kernel
+            float v0 = tot[4 * lane], v1 = tot[4 * lane + 2];
+            const float u0 = tot[4 * lane + 1], u1 = tot[4 * lane + 3];
+            v0 *= 1.0f / (1.0f + expf(-v0)); v0 *= u0;
+            v1 *= 1.0f / (1.0f + expf(-v1)); v1 *= u1;
+            const unsigned pk = (unsigned)f2h(v0) | ((unsigned)f2h(v1) << 16);
+            *reinterpret_cast<unsigned*>(a.out[0] + c0 + 2u * lane) = pk;          // RunState::hb, as the launch sequence leaves it
+#ifdef Q4_PROFILING
+            if (!p.mute)
+#endif
+            store_granule(p.gran + bp + lane, pk, tag);
+        }
+        FPSTAMP(5);
+        FPSTAMP(16);
+        while (rnext < ndp) issue_down(rnext++);
+        wait_vmcnt<0>();
+        FPSTAMP(48);
+        unpack();
+    } else {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.gran, 0, (int)(nch2 * 32u), 0x00020000);
+        const unsigned u0 = gt, u1 = gt + 960u;
+        bool need0 = u0 < nch2, need1 = u1 < nch2;
+        while (rnext < ndp) issue_down(rnext++);           // the rest of this wave's share of the down stream
+        if (p.pre & 2u) wait_vmcnt<0>();                   // (mode bit 1: the first pass leaves when the pieces have landed)
+        if (STAMPS && wave == 1) FPSTAMP(8);
+        unsigned tries = 0, passes = 0;
+        bool failed = false;
+        for (;;) {
+            u32x4 g0, g1, g2, g3;
+            // A chunk that is complete is not read again: its lanes aim past the descriptor's range, which returns zeros without a memory request (no
+            // branch: no copies of a destination register before its data has landed). asm: hipcc must not count these loads, it cannot see the DMA pieces.
+            const unsigned o0 = need0 ? u0 * 32u : 0x7FFFFF00u, o1 = need1 ? u1 * 32u : 0x7FFFFF00u;
+            if (passes == 0 && (p.pre & 1u))      // mode bit 0: the first pass with plain loads -- the L1 is cold for these lines, the XCD's L2 serves the neighbours
+                asm volatile("buffer_load_dwordx4 %0, %4, %6, 0 offen\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen offset:16\n\t"
+                             "buffer_load_dwordx4 %2, %5, %6, 0 offen\n\tbuffer_load_dwordx4 %3, %5, %6, 0 offen offset:16"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(o0), "v"(o1), "s"(rg) : "memory");
+            else                                   // sc1: past the L1 (a line this CU read too early sits there stale)
+                asm volatile("buffer_load_dwordx4 %0, %4, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen offset:16 sc1\n\t"
+                             "buffer_load_dwordx4 %2, %5, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %3, %5, %6, 0 offen offset:16 sc1"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(o0), "v"(o1), "s"(rg) : "memory");
+            if (passes == 0) {                     // under the first pass: the wave's own pieces (requested in front of it: they return first) are unpacked
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                FPSTAMP(48 + wave);
+                unpack();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3) : : "memory");   // ONE statement names the destinations, behind the wait
+            if (need0 && g0[1] == tag && g0[3] == tag && g1[1] == tag && g1[3] == tag) { ha = (u32x4){g0[0], g0[2], g1[0], g1[2]}; need0 = false; }
+            if (need1 && g2[1] == tag && g2[3] == tag && g3[1] == tag && g3[3] == tag) { hb2 = (u32x4){g2[0], g2[2], g3[0], g3[2]}; need1 = false; }
+            const bool pending = __builtin_amdgcn_ballot_w64(need0 || need1) != 0ull;
+            if (STAMPS && passes == 0 && wave == 1) FPSTAMP(6);
+            passes++;
+            if (!pending) break;
+            if (++tries >= FP_POLL_LIMIT || dead != 0u) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (failed && dead == 0u && lane == 0) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (STAMPS) { FPSTAMP(16 + wave); if (wave == 1) { FPSTAMP(7); if (lane == 0) st[12] = passes; } }
+        // stage: down_strip_kernel's (gemv_q4_body's) permuted layout, odd units negated
+        u32x4* xs2 = reinterpret_cast<u32x4*>(smem + P::XS2);
+        float* sx2 = reinterpret_cast<float*>(smem + P::SX2);
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        const unsigned sgn = q4_stage_sign_bits(tid);      // (tid and gt, gt and gt + 960: the same unit parity)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const unsigned u = i ? u1 : u0;
+            u32x4 v = i ? hb2 : ha;
+            v = q4_signed_x(v, sgn);
+            const u32x4 pv = permute_x8(v);
+            float cb = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+            const unsigned j = u >> 2, d = u & 3u;
+            if (u < nch2) {
+                xs2[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+                if (d == 0) sx2[j] = cb * -9.5367431640625e-07f;
+            }
+        }
+    }
+    block_barrier_lds();                               // barrier B: hb staged (every wave's own down pieces have landed and are unpacked)
+    if (wave == 1) FPSTAMP(9);
+
+    // ---- phase 2: down_strip_kernel<3, false>'s units; a k-slot's inputs are read once for both units of the wave
+    uint16_t resid = 0;
+    if ((int)tid < nc2) resid = p.xio[c0d + tid];
+    {
+        const u32x4* xs2 = reinterpret_cast<const u32x4*>(smem + P::XS2);
+        const float* sx2 = reinterpret_cast<const float*>(smem + P::SX2);
+        float* tot2 = reinterpret_cast<float*>(smem + P::TOT2);
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            const bool last = ks == 2;
+            const unsigned unit = ubase + 64u * (unsigned)ks + lane;
+            const bool live = !last || (lane < tail && unit < uend);
+            const unsigned uj = unit < uend ? unit : uend - 1u;
+            const unsigned xrow = ((uj >> 6) << 8) + (uj & 63u);
+            u32x4 X[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) X[d] = xs2[xrow + (d << 6)];
+            const float corr = sx2[uj];
+            const unsigned zsh = ((uj >> 2) & 7u) * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (i < nu2) {
+                    const unsigned lc = ((unsigned)wave >> 1) + 8u * (unsigned)i;
+                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(smem + P::DSIDE_S + (lc * (unsigned)p.sh + (uj >> 2)) * 2u);
+                    const unsigned zw = *reinterpret_cast<const unsigned*>(smem + P::DSIDE_Z + (lc * (unsigned)p.pzh + (uj >> 5)) * 4u);
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        unsigned m0, m1, m2, m3;
+                        if (i == 1 && ks == 2) { const unsigned ww = wlast[d], tt = ww >> 8; m0 = ww & 0x000F000Fu; m1 = ww & 0x00F000F0u; m2 = tt & 0x000F000Fu; m3 = tt & 0x00F000F0u; }
+                        else { m0 = pm[i][ks][4 * d + 0]; m1 = pm[i][ks][4 * d + 1]; m2 = pm[i][ks][4 * d + 2]; m3 = pm[i][ks][4 * d + 3]; }
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(m0), as_h2(X[d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(m1), as_h2(X[d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(m2), as_h2(X[d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(m3), as_h2(X[d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((zw >> zsh) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr, t);
+                    if (last) {         // an ordinary last slot: its lanes past the part's end multiply zero inputs in gemv_q4.h, fma(s, 0, c) = c
+                        const float f = __builtin_fmaf(h2f(sc), t, cs[i]);
+                        cs[i] = live ? f : cs[i];
+                    } else {
+                        cs[i] = __builtin_fmaf(h2f(sc), t, cs[i]);
+                    }
+                }
+            }
+        }
+        const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
+        const int row = lane >> 4;
+        if ((lane & 15u) == 0 && row < nu2) tot2[wave + 16 * row] = total;      // [column][k-part] = unit index
+        if (wave == 1) FPSTAMP(10);
+        if (STAMPS && lane == 0) reinterpret_cast<unsigned long long*>(smem + P::DW + 87u * 1024u)[wave] = wall_clock64();   // (the 88th KiB: free at Llama-2-7B)
+        block_barrier_lds();
+        if ((int)tid < nc2) {
+            float r = tot2[2 * tid];
+            r += tot2[2 * tid + 1];                     // fixed order: k-parts from the lowest up
+            r += h2f(resid);                            // gpu_kernels.h:229-230
+            p.xio[c0d + tid] = f2h(r);                  // :231
+        }
+    }
+    if (STAMPS) {
+        if (wave == 0) FPSTAMP(11);
+        block_barrier_lds();
+        if (p.dbg && tid < 64u) p.dbg[(size_t)blockIdx.x * 64 + tid] = st[tid];
+        if (p.dbg && tid < 16u) p.dbg[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 16 + tid] = reinterpret_cast<unsigned long long*>(smem + P::DW + 87u * 1024u)[tid];   // dots done, per wave
+    }
+}
+#undef FPSTAMP
+
+// Shapes: gate/up K = dim = 4096 (two 1 KiB pieces per column), whole column pairs per CU, 8 .. 28 of them; down projection K = hidden in two k-parts of
+// three slots with an ordinary last one (Llama-2-7B: 172 = 64 + 64 + 44 units), at most 16 output columns per CU whose weights fit the 88 KiB the launch keeps
+// for them; every CU of the device takes one block, so the stream must not be masked. What decides whether the form RUNS is q4_runtime.hip (fusion level 4).
+static bool ffn_pair_shape(const GemvArgs& a, int hidden_k, int dim_n) {
+    const int nb = cu_count();
+    if (!(a.K == 4096 && a.pw4 == 128 && a.sh == 32 && a.pzh == 4) || a.N != hidden_k || (a.N & 1) || stream_cu_count() != nb || g_ablate != 0) return false;
+    const int pairs = a.N / 2;
+    if (pairs / nb < 8 || 2 * divUp(pairs, nb) > STRIP_NCMAX) return false;
+    const QGeom g = make_geom(hidden_k, dim_n);
+    const int ku = (divUp(g.pw4, 2) + 3) & ~3, sh = divUp(ku, 64);
+    if (hidden_k % 32 || sh != 3 || ku - 128 <= 32 || ku * 2 < g.pw4 || divUp(g.pw4, 64) > FP_ROWS) return false;
+    const int nc2 = divUp(dim_n, nb);
+    if (dim_n / nb < 1 || nc2 > FP_NC2MAX || (size_t)divUp(nc2 * g.pw4 * 16, 1024) * 1024 > FfnPairLds::DW_BYTES) return false;
+    return nc2 * g.sh * 2 <= 3072 && nc2 * g.pzh * 4 <= 1024;
+}
+
+}  // namespace q4

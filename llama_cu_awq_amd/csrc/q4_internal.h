@@ -137,6 +137,7 @@ extern int g_cls_argmax;    // exp/lab.hip: profiling knob 12, the greedy sample
 enum { CLS_SYNC_BLOCKS = 1024, CLS_SYNC_WORDS = 2 + 2 * CLS_SYNC_BLOCKS };
 struct GreedyTail { unsigned* words; int* result; volatile int* pPos; int* pPosGpu; int write_token; q4_half* x_next; const q4_half* table; };
 static inline size_t cls_sync_offset(int dim) { return (attention_sync_words(dim) + 1) & ~(size_t)1; }   // 8-byte aligned, behind the attention words
+static inline size_t ffn_pair_sync_offset(int dim) { return cls_sync_offset(dim) + CLS_SYNC_WORDS; }     // (even: granules are 8 bytes)
 int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded);   // q4_kernels.hip
 // Opt `kernel` in to `bytes` of dynamic LDS (more than 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize), once per (kernel, device):
 // a process-wide flag would leave a second device's kernels at 64 KiB after q4_set_device. Not a stream operation: outside any capture.
@@ -147,5 +148,13 @@ extern unsigned long long* g_dbg;   // profiling build: device buffer for time s
 int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pPos, int* pPosGpu, q4_half* x_next, const q4_half* table, int dim);
 int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const QWeight* gate, const QWeight* up,
                      int dim, int hidden);
+// rmsnorm + gate/up + SiLU + down projection + residual as ONE launch (gemv_ffn_pair.h; fusion level 4). Its granules lie behind the model's other
+// hand-off words, at word ffn_pair_sync_offset(dim)
+bool ffn_pair_covers(int dim, int hidden);
+size_t ffn_pair_sync_words(int hidden);
+int ffn_pair_prepare();     // gemv_ffn_pair.hip: LDS opt-in, outside any stream capture
+int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
+                    unsigned* sync, size_t gran_word);
+extern int g_fp_pre, g_fp_mute, g_fp_nt;
 
 }  // namespace q4

@@ -292,6 +292,9 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 14) g_att_ring = slots;     // 0: the split-context attention role takes its K / V rows in registers, 1: on LDS-DMA rings (same bits)
     if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
     if (kind == 11) g_gemv_form = slots;    // a GemvForm (q4_internal.h): 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings
+    if (kind == 16) g_fp_pre = slots;       // FFN pair launch (gemv_ffn_pair.h): down pieces requested in front of a wave's first gather pass
+    if (kind == 17) g_fp_mute = slots;
+    if (kind == 18) g_fp_nt = slots;      // ... the blocks of the next `slots` launches do not publish (a real time-out)
     if (kind == 8) g_ao_guard = slots;      // 0: admit attention -> o-proj grids beyond the resident capacity (forward-progress tests)
     q4_reset_graphs();
 }

@@ -19,6 +19,7 @@ int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the to
 int g_use_graphs = 1;
 int g_quiet = 0;
 static int g_rearm_after = 0;          // > 0: sequences left at fusion level 1 before level 3 is tried again (after a timed-out hand-off)
+static int g_rearm_level = 3;          // the fusion level that comes back when the probation ends
 static int g_rearm_backoff = 16;       // sequences to sit out after the next time-out: doubles every time, so a box that keeps stalling settles at level 1
 static int g_handoff_timeouts = 0;     // timed-out in-launch waits seen by q4_handoff_status since the library was loaded
 char g_last_error[512] = "";
@@ -192,7 +193,7 @@ int q4_memset(void* dst, int value, size_t bytes) {
 // o-proj as one launch on top of that (default). Level 2 (QKV -> attention -> o-proj as one launch) was measured slower than
 // level 1 in round 2 and removed in round 3: the value selects level 1.
 void q4_set_fusion(int level) {
-    g_fusion = level <= 0 ? 0 : level >= 3 ? 3 : 1;
+    g_fusion = level <= 0 ? 0 : level >= 4 ? 4 : level == 3 ? 3 : 1;
     g_rearm_after = 0;          // an explicit choice ends the probation after a time-out (and is the documented way to re-arm at once)
     q4_reset_graphs();
     if (g_stream)
@@ -353,7 +354,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     fclose(file);
     if (rc) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }
     if (!g_quiet) printf("done!\n");
-    if ((rc = down_strip_prepare()) || (rc = cls_strip_prepare())) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }   // (an attribute call: before any graph capture)
+    if ((rc = down_strip_prepare()) || (rc = cls_strip_prepare()) || (rc = ffn_pair_prepare())) { hipFree(slabs.weights); free(w->layers); memset(t, 0, sizeof(*t)); return rc; }   // (an attribute call: before any graph capture)
 
     // malloc_run_state :38-67. att holds n_heads*max(seq_len, dim) halves (the reference's n_heads*dim overflows
     // for seq_len > dim); this build's attention does not use it at all.
@@ -412,7 +413,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     g_slabs[t] = slabs;
     if (rc) { q4_free_transformer(t); return rc; }
     if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
-    const size_t sync_words = cls_sync_offset(p->dim) + CLS_SYNC_WORDS;
+    const size_t sync_words = ffn_pair_sync_offset(p->dim) + ffn_pair_sync_words(p->hidden_dim);
     if (hipMalloc((void**)&slabs.sync, sync_words * sizeof(unsigned)) == hipSuccess) {
         // zeroed on the launch stream and waited for: nothing else orders a null-stream memset before the first launch on a
         // non-blocking g_stream when the caller starts with q4_run_transformer instead of q4_reset_sequence
@@ -537,6 +538,9 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
     const bool ao = g_fusion >= 3 && sync &&
                     attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) >= 0;
 
+    // :326-332 as ONE launch (gemv_ffn_pair.h) where the shapes and the stream admit it; its tag is the same epoch word
+    const bool fp = g_fusion >= 4 && sync && ffn_pair_covers(dim, hidden_dim);
+
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
@@ -545,7 +549,7 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
         if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
-                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table, ao ? sync + SYNC_EPOCH : nullptr));
+                                          dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table, (ao || fp) ? sync + SYNC_EPOCH : nullptr));
         } else {
             Q4_TRY(q4_rmsnorm(s->xb, x, L->rms_att_weight, dim));                                      // :300
             if (dim == kv_dim) {
@@ -567,6 +571,11 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
         Q4_UNLESS(4, q4_matmul_q4(s->x, s->xb, &L->wq_o, dim, dim, 1, -1, nullptr));                   // :323
         }
         Q4_LAYER_DUMP(0);
+        if (fp) {
+            Q4_UNLESS(8, launch_ffn_pair(x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden_dim, sync, ffn_pair_sync_offset(dim)));   // :326-332
+            Q4_LAYER_DUMP(1);
+            continue;
+        }
         if (g_fusion) {
             Q4_UNLESS(8, launch_ffn_fused(s->hb, x, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, dim, hidden_dim));   // :326 + :329
         } else {
@@ -830,7 +839,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
 // ---------------------------------------------------------------------------------------------------
 int q4_reset_sequence(RunState* s, const int* prompt_tokens, int num_prompt_tokens) {
     Q4_HIP(hipMemsetAsync(s->pos, 0, sizeof(int), g_stream));                     // llama2_q4.cu:461
-    if (g_rearm_after > 0 && --g_rearm_after == 0 && g_fusion == 1) { g_fusion = 3; q4_reset_graphs(); }   // probation over
+    if (g_rearm_after > 0 && --g_rearm_after == 0 && g_fusion == 1) { g_fusion = g_rearm_level; q4_reset_graphs(); }   // probation over
     Q4_TRY(clear_handoff_state(s, false));     // counters and granules; the error word [0] stays until q4_handoff_status reads it
     Q4_HIP(hipStreamSynchronize(g_stream));
     s->shared_data->pos = 0;                                                       // :462
@@ -870,6 +879,7 @@ int q4_handoff_status(const RunState* s) {
         Q4_TRY(clear_handoff_state(s, true));
         g_handoff_timeouts++;
         if (g_fusion >= 3) {    // one transient stall (a profiler attaching, a co-tenant) must not cost every later sequence its 3 %
+            g_rearm_level = g_fusion;
             g_fusion = 1;
             g_rearm_after = g_rearm_backoff;
             if (g_rearm_backoff < (1 << 20)) g_rearm_backoff *= 2;
