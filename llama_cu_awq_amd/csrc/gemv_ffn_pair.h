@@ -68,8 +68,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     const int nc = 2 * (int)(pbase + (blockIdx.x < prem ? 1u : 0u));
     const unsigned c0d = blockIdx.x * p.dbase + (blockIdx.x < p.drem ? blockIdx.x : p.drem);   // first down column
     const int nc2 = (int)(p.dbase + (blockIdx.x < p.drem ? 1u : 0u));
-    const int mat = wave & 1;
-    const int nu = (2 * nc - wave + 15) >> 4;
+    // gate/up units: u = gw + 16 i, gw = wave as in gemv_strip.h: where the units do not divide by sixteen the OLDEST waves carry one more -- they also win the
+    // SIMD's issue arbitration. Dealt the other way round (gw = 15 - wave) the block's last wave finished 1.8 us later (tools/lab/ffn_pair_check.py)
+    const int gw = wave;
+    const int mat = gw & 1;
+    const int nu = (2 * nc - gw + 15) >> 4;
     const int npieces = TS * nu;
     const unsigned voff = lane * 16u;
     const bool stager = wave < NSTAGE;
@@ -86,6 +89,11 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             const u32x4* pw = arg_rms + tid;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
         }
+    }
+    unsigned resid_raw = 0u;                             // the residual of this block's down columns (wave 0): x is not rewritten before the launch's last instruction
+    if (wave == 0) {
+        const q4_half* pr = p.xio + c0d + (lane < (unsigned)nc2 ? lane : 0u);
+        asm volatile("global_load_ushort %0, %1, off" : "=&v"(resid_raw) : "v"(pr) : "memory");
     }
     u32x2v ee = {0u, 0u};                                // [0] the error word, [1] the epoch = this launch's tag (advanced by the fused QKV launch in front: >= 1)
     {
@@ -115,7 +123,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
     const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
-    const unsigned soff0 = (c0 + ((unsigned)wave >> 1)) * CB;
+    const unsigned soff0 = (c0 + ((unsigned)gw >> 1)) * CB;
     auto issue2 = [&](int i, int ks) {
         const unsigned dst = ring + (unsigned)((TS * i + ks) & (D - 1)) * 1024u, so = soff0 + (unsigned)i * (8u * CB) + (unsigned)ks * 1024u;
         dma_piece(dst, voff, rw, so);
@@ -145,7 +153,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     float* sx = reinterpret_cast<float*>(smem + L::SX);
     float* part = reinterpret_cast<float*>(smem + L::PART);
     float* tot = reinterpret_cast<float*>(smem + L::TOT);
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(xraw), "+v"(wraw), "+v"(ee) : "n"(D) : "memory");   // all but the weight pieces (every wave has units: ffn_pair_covers)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xraw), "+v"(wraw), "+v"(ee), "+v"(resid_raw) : "n"(D) : "memory");   // all but the weight pieces (every wave has units: ffn_pair_covers)
     if (wave == 0) FPSTAMP(1);
     if (NORM) {
         if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;
@@ -181,8 +189,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             corr[ks] = sx[ks * 64 + lane];
         }
         const unsigned char* wbase = smem + ring + lane * 16u;
-        const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(wave >> 1) * G + (lane >> 2)) * 2u;
-        const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(wave >> 1) * ZW + (lane >> 5)) * 4u;
+        const unsigned char* sbase = smem + L::SIDE_S + mat * L::SIDE_S_BYTES + ((unsigned)(gw >> 1) * G + (lane >> 2)) * 2u;
+        const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(gw >> 1) * ZW + (lane >> 5)) * 4u;
         const unsigned zsh = ((lane >> 2) & 7u) * 4u;
 
         for (int g4 = 0; g4 * 4 < nu; g4++) {
@@ -223,12 +231,12 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             }
             const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
             const int row = lane >> 4;
-            if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[wave + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
+            if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[gw + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
         }
     }
     FPSTAMP(32 + wave);
-    block_barrier_lds();                               // barrier A: the block's gate/up totals are in LDS, its rings are dead
     int rnext = ndp < D ? ndp : D;                     // down pieces this wave has requested so far
+    block_barrier_lds();                               // barrier A: the block's gate/up totals are in LDS, its rings are dead
 
     // ---- the seam
     const unsigned tag = ee[1], dead = ee[0];
@@ -240,9 +248,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     // (the last piece of the second unit stays packed: 128 registers per lane at sixteen waves per CU)
     unsigned pm[2][3][16];
     u32x4 wlast = {0u, 0u, 0u, 0u};
-    auto unpack = [&]() {
+    auto unpack = [&](const int ifirst, const int ilast) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = ifirst; i <= ilast; i++) {
             const unsigned lc = ((unsigned)wave >> 1) + 8u * (unsigned)i;
 #pragma unroll
             for (int ks = 0; ks < 3; ks++) {
@@ -277,11 +285,14 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             store_granule(p.gran + bp + lane, pk, tag);
         }
         FPSTAMP(5);
-        FPSTAMP(16);
+        // (A sentinel poll by this wave -- the last granule of every block's slice, sc1, an LDS flag for the gathering waves when all carry the tag -- was
+        // measured: 256 CUs polling 256 lines slow the down stream itself by 1 us, 976 -> 952 tokens/s. The gathering waves time their first pass by their own
+        // pieces' landing instead: FfnPairArgs::pre.)
         while (rnext < ndp) issue_down(rnext++);
+        FPSTAMP(16);
         wait_vmcnt<0>();
         FPSTAMP(48);
-        unpack();
+        unpack(0, 1);
     } else {
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.gran, 0, (int)(nch2 * 32u), 0x00020000);
         const unsigned u0 = gt, u1 = gt + 960u;
@@ -307,7 +318,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             if (passes == 0) {                     // under the first pass: the wave's own pieces (requested in front of it: they return first) are unpacked
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 FPSTAMP(48 + wave);
-                unpack();
+                unpack(0, 0);                      // (the second unit behind the pass, when its destination registers are free again)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3) : : "memory");   // ONE statement names the destinations, behind the wait
@@ -321,6 +332,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             __builtin_amdgcn_s_sleep(4);
         }
         if (failed && dead == 0u && lane == 0) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unpack(1, 1);
         if (STAMPS) { FPSTAMP(16 + wave); if (wave == 1) { FPSTAMP(7); if (lane == 0) st[12] = passes; } }
         // stage: down_strip_kernel's (gemv_q4_body's) permuted layout, odd units negated
         u32x4* xs2 = reinterpret_cast<u32x4*>(smem + P::XS2);
@@ -348,8 +360,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     if (wave == 1) FPSTAMP(9);
 
     // ---- phase 2: down_strip_kernel<3, false>'s units; a k-slot's inputs are read once for both units of the wave
-    uint16_t resid = 0;
-    if ((int)tid < nc2) resid = p.xio[c0d + tid];
+    const uint16_t resid = (uint16_t)resid_raw;
     {
         const u32x4* xs2 = reinterpret_cast<const u32x4*>(smem + P::XS2);
         const float* sx2 = reinterpret_cast<const float*>(smem + P::SX2);
