@@ -233,14 +233,24 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * attention output's positions (below bin 512 the fused launch's attention role takes 16 positions per wave instruction of a
  * 64-byte V slice, the stand-alone kernel 4; 8 waves instead of 16): logits agree within the model's tolerance in every bin, not
  * bit for bit. After a timed-out hand-off the library runs level 1 for the next 16 sequences (32, 64, ... after further
- * time-outs), then tries level 3 again; q4_set_fusion(3) re-arms it at once. Resets captured graphs. */
+ * time-outs), then tries level 3 again; q4_set_fusion(3) re-arms it at once. Resets captured graphs.
+ * 4: additionally the FFN half of a layer (rmsnorm + gate/up + SiLU + down projection + residual add, llama2_q4.cu:326-332) as ONE
+ * launch where q4_ffn_pair_covers says so (Llama-2-7B's dim / hidden_dim): one block per CU computes its slice of hb, hands it to every
+ * other CU inside the launch and multiplies its columns of the down projection, whose weights it has meanwhile streamed into LDS;
+ * 3 launches/layer, bit-identical to levels 1 / 3 (same bounded waits, same fallback after a time-out). */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
+/* 1: at fusion level 4 a layer's FFN half of these sizes runs as one launch on the current device and stream (csrc/gemv_ffn_pair.h) */
+int q4_ffn_pair_covers(int dim, int hidden_dim);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches with the exact context length (the
  * reference's other path, :374); 2: eager launches with the graph path's sequence-length bin -- exactly what the graphs run, one launch
  * at a time (the mode to profile in: rocprofv3 cannot trace inside a graph capture) */
 void q4_set_use_graphs(int enable);
 void q4_reset_graphs(void);   /* drop captured graphs (main() cleanup llama2_q4.cu:713-716) */
+/* Graphs captured so far in this process. Captured graphs are kept per model (RunState), for up to four live models: a host that alternates
+ * them replays each one's graphs; beyond four the least recently used model's graphs are dropped and captured again on its next turn --
+ * this counter is how a host sees that happen. */
+int q4_graph_captures(void);
 
 /* build_sampler / destroy_sampler sampler.h:15-29; random_u32 / random_f32 :31-40; sample :43-82 */
 int build_sampler(Sampler* sampler, int vocab_size, float temperature, float topp, unsigned long long rng_seed);

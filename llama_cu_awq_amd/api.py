@@ -54,7 +54,7 @@ SYMBOLS = [
     "q4_get_stream", "q4_stream_synchronize", "q4_device_synchronize", "q4_malloc", "q4_free", "q4_memcpy_h2d",
     "q4_memcpy_d2h", "q4_memset", "q4_rmsnorm", "q4_matmul_f16", "q4_matmul_q4", "q4_qkv_matvec", "q4_ffn_matvec_silu",
     "q4_rope_rotation", "q4_multi_head_attention", "q4_copy_embedding", "q4_convert_fp16_to_fp32", "q4_argmax",
-    "q4_run_llama_network", "q4_run_transformer", "q4_run_transformer_at", "q4_wait_pos", "q4_steps_that_fit", "q4_run_transformer_steps", "q4_set_fusion", "q4_get_fusion", "q4_set_use_graphs", "q4_reset_graphs",
+    "q4_run_llama_network", "q4_run_transformer", "q4_run_transformer_at", "q4_wait_pos", "q4_steps_that_fit", "q4_run_transformer_steps", "q4_set_fusion", "q4_get_fusion", "q4_ffn_pair_covers", "q4_set_use_graphs", "q4_reset_graphs", "q4_graph_captures",
     "build_sampler", "destroy_sampler", "random_u32", "random_f32", "q4_sample", "q4_build_transformer",
     "q4_free_transformer", "q4_set_quiet", "q4_transformer_new", "q4_transformer_delete", "q4_transformer_config",
     "q4_transformer_state", "q4_transformer_weights", "q4_sampler_new", "q4_sampler_delete", "q4_reset_sequence",
@@ -117,6 +117,8 @@ def lib():
     L.q4_run_transformer.argtypes = [i, C.POINTER(Config), C.POINTER(RunState), C.POINTER(TransformerWeights), i, vp]
     L.q4_set_fusion.argtypes = [i]
     L.q4_set_fusion.restype = None
+    if hasattr(L, "q4_ffn_pair_covers"):           # (older builds under tools/ab.py do not have it)
+        L.q4_ffn_pair_covers.argtypes = [i, i]
     L.q4_set_use_graphs.argtypes = [i]
     L.q4_set_use_graphs.restype = None
     L.q4_reset_graphs.restype = None

@@ -245,9 +245,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     const unsigned nch2 = (unsigned)p.Kd >> 3;
     const unsigned tail = ku - 128u;
     // phase 2's weights, unpacked while the wave waits for the vector: [unit][slot][dword] x {n0 n4, n1 n5 << 4, n2 n6, n3 n7 << 4} as fp16 denormal pairs
-    // (the last piece of the second unit stays packed: 128 registers per lane at sixteen waves per CU)
     unsigned pm[2][3][16];
-    u32x4 wlast = {0u, 0u, 0u, 0u};
     auto unpack = [&](const int ifirst, const int ilast) {
 #pragma unroll
         for (int i = ifirst; i <= ilast; i++) {
@@ -258,7 +256,6 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                 const unsigned uj = unit < uend ? unit : uend - 1u;
                 u32x4 w = {0u, 0u, 0u, 0u};
                 if (i < nu2) w = *reinterpret_cast<const u32x4*>(smem + P::DW + (lc * (unsigned)p.pw4 + uj) * 16u);
-                if (i == 1 && ks == 2) { wlast = w; continue; }
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const unsigned ww = w[d], tt = ww >> 8;
@@ -267,6 +264,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                     pm[i][ks][4 * d + 2] = tt & 0x000F000Fu;
                     pm[i][ks][4 * d + 3] = tt & 0x00F000F0u;
                 }
+                // the masks are computed HERE, while the wave waits for the vector: left alone hipcc sinks them behind barrier B, next to the dot products (seen in the ISA)
+                asm volatile("" : "+v"(pm[i][ks][0]), "+v"(pm[i][ks][1]), "+v"(pm[i][ks][2]), "+v"(pm[i][ks][3]), "+v"(pm[i][ks][4]), "+v"(pm[i][ks][5]), "+v"(pm[i][ks][6]), "+v"(pm[i][ks][7]),
+                             "+v"(pm[i][ks][8]), "+v"(pm[i][ks][9]), "+v"(pm[i][ks][10]), "+v"(pm[i][ks][11]), "+v"(pm[i][ks][12]), "+v"(pm[i][ks][13]), "+v"(pm[i][ks][14]), "+v"(pm[i][ks][15]));
             }
         }
     };
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const unsigned u0 = gt, u1 = gt + 960u;
         bool need0 = u0 < nch2, need1 = u1 < nch2;
         while (rnext < ndp) issue_down(rnext++);           // the rest of this wave's share of the down stream
-        if (p.pre & 2u) wait_vmcnt<0>();                   // (mode bit 1: the first pass leaves when the pieces have landed)
+        if (p.pre & 2u) wait_vmcnt_upto15((int)((p.pre >> 4) & 15u));   // (mode bit 1: the first pass leaves when all but `pre >> 4` of the wave's pieces have landed)
         if (STAMPS && wave == 1) FPSTAMP(8);
         unsigned tries = 0, passes = 0;
         bool failed = false;
@@ -366,6 +366,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const float* sx2 = reinterpret_cast<const float*>(smem + P::SX2);
         float* tot2 = reinterpret_cast<float*>(smem + P::TOT2);
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef Q4_PROFILING
+        if (!(p.pre & 8u))      // (ablation, profiling build: phase 2 without its dot products -- what they cost the token; results are garbage)
+#endif
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
             const bool last = ks == 2;
@@ -388,8 +391,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
                         unsigned m0, m1, m2, m3;
-                        if (i == 1 && ks == 2) { const unsigned ww = wlast[d], tt = ww >> 8; m0 = ww & 0x000F000Fu; m1 = ww & 0x00F000F0u; m2 = tt & 0x000F000Fu; m3 = tt & 0x00F000F0u; }
-                        else { m0 = pm[i][ks][4 * d + 0]; m1 = pm[i][ks][4 * d + 1]; m2 = pm[i][ks][4 * d + 2]; m3 = pm[i][ks][4 * d + 3]; }
+                        m0 = pm[i][ks][4 * d + 0]; m1 = pm[i][ks][4 * d + 1]; m2 = pm[i][ks][4 * d + 2]; m3 = pm[i][ks][4 * d + 3];
                         acc_e = __builtin_amdgcn_fdot2(as_h2(m0), as_h2(X[d][0]), acc_e, false);
                         acc_o = __builtin_amdgcn_fdot2(as_h2(m1), as_h2(X[d][1]), acc_o, false);
                         acc_e = __builtin_amdgcn_fdot2(as_h2(m2), as_h2(X[d][2]), acc_e, false);

@@ -596,13 +596,13 @@ __global__ void __launch_bounds__((LaunchTraits<MODE, SLOTS, COLS, KS>::MAX_THRE
     gemv_q4_body<MODE, SLOTS, COLS, NORM, ABL, KS, HALF, ROLE_NONE>(a, blockIdx.x, blockIdx.y, Handoff{});
 }
 
+// CUs of the CURRENT device (per ordinal: a process may drive several devices through q4_set_device)
 static inline int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
-    return n;
+    static int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n[dev] == 0 && (hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n[dev] <= 0)) n[dev] = 256;
+    return n[dev];
 }
 
 // host-side dispatch -------------------------------------------------------------------------------

@@ -92,10 +92,46 @@ int lds_opt_in(const void* kernel, size_t bytes) {
     return Q4_OK;
 }
 
-// graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampling outside the graph
-static hipGraphExec_t g_graphs[Q4_MAX_GRAPHS][16];   // [bin][variant | 8: Q4_MULTI_STEPS steps per graph]
-static bool g_captured[Q4_MAX_GRAPHS][16];
-static const void* g_graph_owner = nullptr;
+// graphs: [bin][variant]; variant bit0 = gen_token, bit1 = copyLogits, bit2 = sampled (the sampler launch, its temperature / top-p / coin ring baked in),
+// bit3 = Q4_MULTI_STEPS steps per graph. A captured graph holds one model's pointers, so the sets are kept PER MODEL (its RunState): a host that alternates
+// a few models on one GPU replays each one's graphs (llama2_q4.cu:342-344 keeps one set for its one model); beyond GRAPH_OWNERS live models the least
+// recently used set is dropped and captured again on its next turn (q4_graph_captures counts: a host can see it happen).
+enum { GRAPH_OWNERS = 4 };
+struct GraphSet {
+    const void* owner;
+    unsigned long long used;
+    hipGraphExec_t exec[Q4_MAX_GRAPHS][16];
+    bool captured[Q4_MAX_GRAPHS][16];
+    const Sampler* sampler;            // what the set's sampled graphs have baked in
+    float temperature, topp;
+    const float* coins;
+};
+static GraphSet g_sets[GRAPH_OWNERS];
+static unsigned long long g_set_clock = 0;
+static int g_graph_captures = 0;
+static void drop_graphs(GraphSet& gs, bool sampled_only) {
+    for (int i = 0; i < Q4_MAX_GRAPHS; i++)
+        for (int v = 0; v < 16; v++)
+            if (gs.captured[i][v] && (!sampled_only || (v & 4))) {
+                hipGraphExecDestroy(gs.exec[i][v]);
+                gs.captured[i][v] = false;
+            }
+    if (!sampled_only) gs.owner = nullptr;
+    gs.sampler = nullptr; gs.coins = nullptr;
+}
+static GraphSet& graph_set_of(const void* owner) {
+    GraphSet* pick = nullptr;
+    for (GraphSet& gs : g_sets)
+        if (gs.owner == owner) { pick = &gs; break; }
+    if (!pick) {
+        for (GraphSet& gs : g_sets)
+            if (!pick || (gs.owner == nullptr && pick->owner != nullptr) || (((gs.owner == nullptr) == (pick->owner == nullptr)) && gs.used < pick->used)) pick = &gs;
+        if (pick->owner) drop_graphs(*pick, false);
+        pick->owner = owner;
+    }
+    pick->used = ++g_set_clock;
+    return *pick;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -200,6 +236,7 @@ void q4_set_fusion(int level) {
         for (auto& kv : g_sync_by_state) (void)clear_handoff_state(kv.first, false);   // no stale counters / granules across a change of launch sequence
 }
 int q4_get_fusion(void) { return g_fusion; }
+int q4_ffn_pair_covers(int dim, int hidden_dim) { return ffn_pair_covers(dim, hidden_dim) ? 1 : 0; }
 // 1: captured graphs (USE_CUDA_GRAPHS, llama2_q4.cu:33); 0: eager launches with the exact context length (the reference's other path, :374);
 // 2: eager launches with the graph path's sequence-length BIN -- what the graphs run, one launch at a time: the mode to profile in
 // (rocprofv3 cannot trace inside a graph capture; with 0 the attention launch picks its form from the context length, not from the bin)
@@ -207,14 +244,9 @@ void q4_set_use_graphs(int enable) { g_use_graphs = enable == 2 ? 2 : enable ? 1
 void q4_set_quiet(int quiet) { g_quiet = quiet; }
 
 void q4_reset_graphs(void) {
-    for (int i = 0; i < Q4_MAX_GRAPHS; i++)
-        for (int v = 0; v < 16; v++)
-            if (g_captured[i][v]) {
-                hipGraphExecDestroy(g_graphs[i][v]);
-                g_captured[i][v] = false;
-            }
-    g_graph_owner = nullptr;
+    for (GraphSet& gs : g_sets) drop_graphs(gs, false);
 }
+int q4_graph_captures(void) { return g_graph_captures; }
 
 int q4_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes) {
     int dev = 0;
@@ -435,7 +467,8 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
 
 void q4_free_transformer(Transformer* t) {                                        // :428-432
     if (!t) return;
-    if (g_graph_owner == (const void*)&t->state) q4_reset_graphs();   // the owner is recorded as the RunState (run_transformer_at)
+    for (GraphSet& gs : g_sets)
+        if (gs.owner == (const void*)&t->state) drop_graphs(gs, false);   // the owner is recorded as the RunState (run_transformer_at)
     auto it = g_slabs.find(t);
     if (it != g_slabs.end()) {
         hipDeviceSynchronize();
@@ -657,9 +690,6 @@ int build_sampler(Sampler* sampler, int vocab_size, float temperature, float top
 // eight per replay like greedy ones. (The Sampler struct is the reference's: the ring lives beside it.)
 struct CoinRing { float* host; float* dev; int cap; };
 static std::map<const Sampler*, CoinRing> g_coin_rings;
-static const Sampler* g_graph_sampler = nullptr;     // what the captured sampled graphs have baked in
-static float g_graph_temperature = 0.f, g_graph_topp = 0.f;
-static const float* g_graph_coins = nullptr;
 static int coin_ring_for(const Sampler* sampler, int positions, CoinRing** out) {
     CoinRing& r = g_coin_rings[sampler];
     if (r.cap < positions) {
@@ -681,7 +711,8 @@ static int coin_ring_for(const Sampler* sampler, int positions, CoinRing** out) 
 void destroy_sampler(Sampler* sampler) {
     auto cr = g_coin_rings.find(sampler);
     if (cr != g_coin_rings.end()) {
-        if (g_graph_sampler == sampler) { q4_reset_graphs(); g_graph_sampler = nullptr; g_graph_coins = nullptr; }
+        for (GraphSet& gs : g_sets)
+            if (gs.sampler == sampler) drop_graphs(gs, true);
         if (g_stream) hipStreamSynchronize(g_stream);
         if (cr->second.host) hipHostFree(cr->second.host);
         if (cr->second.dev) hipFree(cr->second.dev);
@@ -770,7 +801,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
     if (pos < 0 || pos + nsteps > p->seq_len) return Q4_ERR_ARG;
 
     if (g_use_graphs == 1) {
-        if (g_graph_owner != (const void*)s) { q4_reset_graphs(); g_graph_owner = s; }
+        GraphSet& gs = graph_set_of(s);
         // Unlike the reference, the greedy sampler kernel and the fp32 logits copy are part of the captured
         // graph (one launch per token instead of up to three); the variant index keeps them apart.
         const int variant = (gen_token ? 1 : 0) | (copyLogits ? 2 : 0) | (greedy ? 0 : 4) | (nsteps > 1 ? 8 : 0);
@@ -778,15 +809,12 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
         if (!greedy) {     // the sampling kernel is part of the graph: its temperature, top-p, scratch and coin ring are baked in
             Q4_TRY(coin_ring_for(pSampler, p->seq_len, &ring));
             Q4_TRY(q4_sample_topp_prepare(pSampler));     // scratch + LDS opt-in: not capturable
-            if (g_graph_sampler != pSampler || g_graph_temperature != pSampler->temperature || g_graph_topp != pSampler->topp ||
-                g_graph_coins != ring->dev) {
-                for (int i = 0; i < Q4_MAX_GRAPHS; i++)
-                    for (int v = 4; v < 16; v++)
-                        if ((v & 4) && g_captured[i][v]) { hipGraphExecDestroy(g_graphs[i][v]); g_captured[i][v] = false; }
-                g_graph_sampler = pSampler; g_graph_temperature = pSampler->temperature; g_graph_topp = pSampler->topp; g_graph_coins = ring->dev;
+            if (gs.sampler != pSampler || gs.temperature != pSampler->temperature || gs.topp != pSampler->topp || gs.coins != ring->dev) {
+                drop_graphs(gs, true);
+                gs.sampler = pSampler; gs.temperature = pSampler->temperature; gs.topp = pSampler->topp; gs.coins = ring->dev;
             }
         }
-        if (!g_captured[graphIndex][variant]) {                                    // :362-371
+        if (!gs.captured[graphIndex][variant]) {                                   // :362-371
             hipGraph_t graph = nullptr;
             Q4_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
             int rc = 0;
@@ -816,9 +844,10 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             hipError_t e = hipStreamEndCapture(g_stream, &graph);
             if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
             Q4_HIP(e);
-            Q4_HIP(hipGraphInstantiate(&g_graphs[graphIndex][variant], graph, nullptr, nullptr, 0));
+            Q4_HIP(hipGraphInstantiate(&gs.exec[graphIndex][variant], graph, nullptr, nullptr, 0));
             Q4_HIP(hipGraphDestroy(graph));
-            g_captured[graphIndex][variant] = true;
+            gs.captured[graphIndex][variant] = true;
+            g_graph_captures++;
         }
         // one coin per step, drawn whether the step samples or not (sampler.h:45, P8); the sampled steps' coins go to the ring
         for (int i = 0; i < nsteps; i++) {
@@ -826,7 +855,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             if (ring) ring->host[pos + i] = coin;
         }
         if (ring) Q4_HIP(hipMemcpyAsync(ring->dev + pos, ring->host + pos, (size_t)nsteps * sizeof(float), hipMemcpyHostToDevice, g_stream));
-        Q4_HIP(hipGraphLaunch(g_graphs[graphIndex][variant], g_stream));          // :372 (:384: the sampler launch is in the graph)
+        Q4_HIP(hipGraphLaunch(gs.exec[graphIndex][variant], g_stream));          // :372 (:384: the sampler launch is in the graph)
         return Q4_OK;
     }
     GreedyTail tail = {nullptr, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token, nullptr, w->token_embedding_table};

@@ -490,3 +490,39 @@ def test_held_back_oproj_weight_requests_are_bit_neutral(q4, model, steps):
         assert outs[hold][1] == outs[0][1], "token rings differ (hold %d)" % hold
         for a, b, pos in zip(outs[0][0], outs[hold][0], cps):
             assert np.array_equal(a, b), "hold %d: logits differ at position %d" % (hold, pos)
+
+
+def test_ffn_pair_launch_times_out_cleanly_and_its_gather_modes_agree(q4, tmp_path):
+    """The FFN half of a layer as one launch (csrc/gemv_ffn_pair.h, fusion level 4). (1) Its gather modes (profiling knob 16: first pass with sc1
+    or plain loads, at once or when the wave's own down pieces have landed) are timing choices: token rings and logits identical. (2) A REAL
+    time-out: the blocks of one launch do not publish (knob 17), every bounded wait runs out, the error word is set, launches queued behind it
+    do not spin again; q4_generate_ids redoes the sequence at fusion level 1 with the tokens of a clean run; q4_set_fusion(4) re-arms the launch."""
+    L = q4.lib()
+    p = str(tmp_path / "ffn_pair7b.bin")
+    synth.write_model(p, "ffn_pair7b", seed=11)
+    prompt = [1, 5, 9]
+    try:
+        L.q4_set_fusion(1)
+        t = q4.Transformer(p)
+        want = t.generate_ids(prompt, 40)[0].copy()
+        before = L.q4_handoff_timeouts()
+        for mode in (3, 0, 1, 2, 19):
+            L.q4_set_fusion(4)
+            L.q4_set_gemv_early(16, mode)
+            assert np.array_equal(t.generate_ids(prompt, 40)[0], want), mode          # bit-identical launches: the same greedy ring
+            assert L.q4_handoff_timeouts() == before and L.q4_get_fusion() == 4
+        L.q4_set_gemv_early(16, 3)
+        L.q4_set_gemv_early(17, 1)                                      # the next FFN pair launch is captured mute
+        got = t.generate_ids(prompt, 40)[0]
+        assert np.array_equal(got, want)
+        assert L.q4_handoff_timeouts() == before + 1 and L.q4_get_fusion() == 1
+        q4.check(L.q4_handoff_status(t.state))                          # reported once, state clean now
+        assert np.array_equal(t.generate_ids(prompt, 12)[0], want[:13]) and L.q4_get_fusion() == 1     # probation (its length is process-wide state: see the test above)
+        L.q4_set_fusion(4)                                              # re-armed at once by an explicit choice
+        assert np.array_equal(t.generate_ids(prompt, 40)[0], want)
+        assert L.q4_get_fusion() == 4 and L.q4_handoff_timeouts() == before + 1
+        t.close()
+    finally:
+        L.q4_set_gemv_early(17, 0)
+        L.q4_set_gemv_early(16, 3)
+        L.q4_set_fusion(q4.DEFAULT_FUSION)

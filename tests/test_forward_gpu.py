@@ -370,3 +370,43 @@ def test_sampler_rng_after_an_early_stop_matches_one_draw_per_executed_step(q4, 
         got = C.cast(t.sampler, C.POINTER(SamplerStruct)).contents.rng_state
         assert got == state.value, (stop, got, state.value)
         t.close()
+
+
+def test_two_models_alternate_without_recapture(q4, models):
+    """Captured graphs are kept per model (csrc/q4_runtime.hip, GraphSet): a host that alternates two Transformers step by step replays each one's
+    graphs instead of capturing them again on every switch (q4_graph_captures counts), and every token equals the model's own stepwise run. A fifth
+    live model evicts the least recently used set, which is captured again on its next turn."""
+    L = q4.lib()
+    names = ["tiny", "tiny_gqa"]
+    prompt = [1, 17, 300, 45, 9]
+    want = {}
+    for n in names:                                   # each model alone
+        t = q4.Transformer(models[n])
+        want[n] = list(t.generate_ids(prompt, 34)[0])
+        t.close()
+    ts = {n: q4.Transformer(models[n]) for n in names}
+    for n in names:
+        ts[n].reset(prompt)
+    c0 = L.q4_graph_captures()
+    for pos in range(30):
+        for n in names:                               # 30 alternating steps
+            ts[n].run_transformer(pos >= len(prompt) - 1)
+    q4.synchronize()
+    used = L.q4_graph_captures() - c0
+    # tiny models: one bin (seq_len 64), two variants each (prompt steps, generated steps) -> four captures for sixty alternating steps
+    assert used == 4, used
+    for n in names:
+        assert [int(ts[n].token(i)) for i in range(31)] == want[n][:31], n
+    # more live models than the cache holds: still correct, the evicted model captures again
+    extra = [q4.Transformer(models[x]) for x in ("small", "head96", "head80_gqa")]
+    for t in extra:
+        t.reset(prompt)
+        t.run_transformer(False)
+    q4.synchronize()
+    c1 = L.q4_graph_captures()
+    ts["tiny"].run_transformer(True)                  # `tiny` was the least recently used of five: its set is gone
+    q4.synchronize()
+    assert L.q4_graph_captures() == c1 + 1
+    assert int(ts["tiny"].token(31)) == want["tiny"][31]
+    for t in list(ts.values()) + extra:
+        t.close()

@@ -59,6 +59,7 @@ for pre in pres:
         t.generate_ids(prompt, ntok)
         res[lvl].append(max(t.generate_ids(prompt, ntok)[1] for _ in range(3)))
   for lvl in (3, 4):
+    print("per token: level 3 %.4f ms, level 4 %.4f ms, difference %.1f us" % (1e3 / np.median(res[3]), 1e3 / np.median(res[4]), 1e6 / np.median(res[3]) - 1e6 / np.median(res[4]))) if lvl == 4 else None
     print("pre %d level %d  -n %d  best-of-3 tokens/s per round: %s   median %.1f" % (pre, lvl, ntok, " ".join("%.1f" % v for v in res[lvl]), float(np.median(res[lvl]))), flush=True)
   print("time-outs:", L.q4_handoff_timeouts(), "fusion:", L.q4_get_fusion())
 
