@@ -51,12 +51,15 @@ def kernel_bytes(cfg):
         3: ("qkv_rmsnorm_rope_q4", 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2),
         4: ("gemv_q4_oproj_accum", qweight_bytes(d, d) + d * 2 + 2 * d * 2),
         5: ("classifier_f16", v * d * 2 + d * 2 + v * 2),
+        # fusion level 4: rmsnorm + gate/up + SiLU + down + residual as ONE launch (csrc/gemv_ffn_pair.h): the three QWeights, x and the norm weights in,
+        # the residual in, x out, and RunState::hb, which the launch still leaves behind (its in-launch hand-off of hb is not algorithmic traffic)
+        10: ("ffn_rmsnorm_gate_up_silu_down_accum_q4", 2 * qweight_bytes(d, h) + qweight_bytes(h, d) + 4 * d * 2 + h * 2),
     }
 
 
-def sample_sclk_ghz(run, seconds=2.5):
-    """Shader clock while `run()` keeps the token loop busy: rocm-smi polled from a side thread (the timed region is never sampled: the
-    poll costs host time). Returns (GHz, source); without rocm-smi the 2.35 GHz of tools/clock_probe.sh (round 4: 2325-2364 MHz in the loop)."""
+def sample_sclk_ghz(run, seconds=2.5, device=0):
+    """Shader clock of `device` while `run()` keeps the token loop busy: rocm-smi polled from a side thread (the timed region is never sampled: the
+    poll costs host time). Returns (GHz, source): the MEDIAN of the samples; (None, reason) when rocm-smi is not usable."""
     import re
     import subprocess
     import threading
@@ -65,7 +68,7 @@ def sample_sclk_ghz(run, seconds=2.5):
     def poll():
         while not stop.is_set():
             try:
-                out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                out = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks"], capture_output=True, text=True, timeout=10).stdout
                 mm = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", out)
                 if mm:
                     vals.append(int(mm.group(1)))
@@ -80,8 +83,9 @@ def sample_sclk_ghz(run, seconds=2.5):
     th.join(timeout=15)
     vals = [v for v in vals if v > 500]
     if vals:
-        return max(vals) / 1000.0, "rocm-smi --showclocks during the token loop (%d samples, max of %s MHz)" % (len(vals), sorted(set(vals)))
-    return 2.35, "tools/clock_probe.sh, round 4: sclk 2325-2364 MHz in the token loop (rocm-smi not usable here)"
+        vals.sort()
+        return vals[len(vals) // 2] / 1000.0, "rocm-smi -d %d --showclocks during the token loop (%d samples, median of %s MHz)" % (device, len(vals), sorted(set(vals)))
+    return None, "rocm-smi not usable here"
 
 
 def main():
@@ -210,7 +214,11 @@ def main():
     roofline = None
     if rank == 0:
         tr.reset(PROMPT_IDS)          # the timed kernels address the KV cache at the device position: back to 0 (after -n 2048 it is seq_len)
+        pair = L.q4_get_fusion() >= 4 and L.q4_ffn_pair_covers(cfg.dim, cfg.hidden_dim) == 1    # the FFN half of a layer runs as one launch
+        dom_id = 10 if pair else 0                                                               # the decode path's dominant launch
         for kid, (name, nbytes) in kb.items():
+            if kid == 10 and not pair:
+                continue
             tr.bench_kernel(kid, 32)   # warm
             avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
             kernels[name] = {"us": round(avg, 3), "min_us": round(mn, 3), "bytes": nbytes, "GBps": round(nbytes / avg / 1e3, 1)}
@@ -225,30 +233,32 @@ def main():
             api.synchronize()
         pos_first = tr.pos()
         net_avg, net_min, net_max, net_n = tr.bench_in_network(8, 16)
-        graph_us = tr.bench_kernel_graph(0, 32, 20)
+        graph_us = tr.bench_kernel_graph(dom_id, 32, 20)
         # The roofline is priced on the kernel's own duration. Two measurements exist: HIP events around every gate/up launch of
         # 16 untraced eager decode steps (live, here), and rocprofv3's kernel trace of a whole eager -n 256 decode (committed:
         # profiles/r03_kernel_stats_7b_256_eager.csv, ~6 % longer: every dispatch is intercepted and serialised under the
         # tracer). The line takes the LARGER of the two, so it never claims more than the committed profile supports; the
         # per-launch cost inside a hipGraph (kernel + boundary) is reported next to it.
         rocprof_us, rocprof_src = None, None
-        for tag in ("r05", "r04", "r03", "r02"):
+        for tag in ("r06", "r05", "r04", "r03", "r02"):
             cpath = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s_%d_eager.csv" % (tag, args.model, ntok))
             if os.path.exists(cpath):
                 import csv
                 for r in csv.DictReader(open(cpath)):
-                    if "gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]:   # the fused gate/up launch (wide matrices: the strips form, csrc/gemv_strip.h)
+                    if ("ffn_pair_kernel<" in r["kernel"]) if pair else ("gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]):   # the dominant launch: the FFN pair (csrc/gemv_ffn_pair.h), else the fused gate/up launch (csrc/gemv_strip.h)
                         rocprof_us, rocprof_src = float(r["avg_us"]), "profiles/" + os.path.basename(cpath)
                         break
             if rocprof_us is not None:
                 break
         kernel_us = max(net_avg, rocprof_us) if rocprof_us else net_avg
-        dom = {"us": round(kernel_us, 3), "GBps": round(kb[0][1] / kernel_us / 1e3, 1)}
+        dom = {"us": round(kernel_us, 3), "GBps": round(kb[dom_id][1] / kernel_us / 1e3, 1)}
         in_network = {}
         per_kernel = {}
         kv_dim = cfg.dim * cfg.n_kv_heads // cfg.n_heads
         for cls, nm, kid in ((1, "qkv_rmsnorm_rope_q4", 3), (6, "attention+oproj_accum (one launch, fusion level 3)", None),
                              (16, "gemv_q4_hidden_to_dim_accum", 2), (32, "final_rmsnorm+classifier_f16", 5)):
+            if cls == 16 and pair:      # the down projection is inside the FFN pair launch
+                continue
             p0_ = tr.pos()
             a_, mn_, mx_, n_ = tr.bench_in_network(cls, 4)
             in_network[nm] = round(a_, 3)
@@ -263,12 +273,20 @@ def main():
                 nb_ += 3 * cfg.dim * 2
             per_kernel[nm] = {"hip_event_us": round(a_, 3), "bytes": nb_, "GBps": round(nb_ / a_ / 1e3, 1),
                               "frac": round(nb_ / a_ / 1e3 / HBM_PEAK_GBS, 4), "launches": n_, "first_position": p0_}
-        in_network[kb[0][0]] = round(net_avg, 3)
-        per_kernel[kb[0][0]] = {"hip_event_us": round(net_avg, 3), "graph_us": round(graph_us, 3), "bytes": kb[0][1],
-                                "frac": round(kb[0][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
+        in_network[kb[dom_id][0]] = round(net_avg, 3)
+        per_kernel[kb[dom_id][0]] = {"hip_event_us": round(net_avg, 3), "graph_us": round(graph_us, 3), "bytes": kb[dom_id][1],
+                                     "frac": round(kb[dom_id][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
+        if pair:    # what the launch replaced, on this box: the two launches of fusion level 3, inside the same eager network
+            L.q4_set_fusion(3)
+            gu_, _, _, ngu_ = tr.bench_in_network(8, 8)
+            dn_, _, _, ndn_ = tr.bench_in_network(16, 8)
+            L.q4_set_fusion(4)
+            per_kernel[kb[dom_id][0]]["replaces"] = {"gate_up_launch_us": round(gu_, 3), "down_launch_us": round(dn_, 3), "sum_us": round(gu_ + dn_, 3),
+                                                     "frac_of_the_two": round(kb[dom_id][1] / (gu_ + dn_) / 1e3 / HBM_PEAK_GBS, 4),
+                                                     "note": "fusion level 3's gate/up launch (csrc/gemv_strip.h) and down projection (csrc/gemv_q4.h, K split) by HIP events in the same network"}
         traffic, traffic_src = None, None
         # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
-        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.model == "7b":
                 tj_all = json.load(open(tpath))
@@ -276,7 +294,7 @@ def main():
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
                             "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
-                            kb[0][0]: ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
+                            kb[dom_id][0]: ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
                 for nm_, pre_ in prefixes.items():
                     ratios = [e_["traffic_over_algorithmic"] for k_, e_ in tj_all.get("%s_n%d" % (args.model, ntok), {}).items()
                               if isinstance(e_, dict) and k_.replace("q4::", "").startswith(pre_) and "traffic_over_algorithmic" in e_]   # (str.startswith takes a tuple too)
@@ -286,42 +304,46 @@ def main():
                 if "traffic_bytes_per_launch" in tj:
                     traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % tname
                     break
-        roofline = {"bound": "hbm", "kernel": kb[0][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": kb[dom_id][0], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "bytes_per_launch": kb[0][1], "avg_launch_us": dom["us"],
+                    "bytes_per_launch": kb[dom_id][1], "avg_launch_us": dom["us"],
                     "timing": "kernel duration = max(live HIP-event average, rocprofv3 average of the committed eager trace)",
                     "hip_event_us": round(net_avg, 3), "hip_event_min_us": round(net_min, 3), "hip_event_launches": net_n,
-                    "hip_event_frac": round(kb[0][1] / net_avg / 1e3 / HBM_PEAK_GBS, 4),
+                    "hip_event_frac": round(kb[dom_id][1] / net_avg / 1e3 / HBM_PEAK_GBS, 4),
                     "hip_event_timing": "HIP events (hipExtLaunchKernelGGL start/stop) on the launch stream, every gate/up "
                                         "launch of 16 eager decode steps from position 64 (untraced; excludes the boundary)",
                     "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src,
                     "graph_us_per_launch": round(graph_us, 3),
-                    "graph_frac": round(kb[0][1] / graph_us / 1e3 / HBM_PEAK_GBS, 4),
+                    "graph_frac": round(kb[dom_id][1] / graph_us / 1e3 / HBM_PEAK_GBS, 4),
                     "graph_timing": "per launch inside a hipGraph (the mode the token loop runs in): 20 replays of a 32-launch "
                                     "graph over the ring of the layers' weights, kernel + boundary",
-                    "isolated_ring_us": kernels[kb[0][0]]["us"],
+                    "isolated_ring_us": kernels[kb[dom_id][0]]["us"],
                     "per_kernel": per_kernel}
         # what else bounds the kernel: the committed SQ counters of the same launch (tools/profile_sq.sh), priced at the shader clock read
         # from rocm-smi while the token loop runs. The int4 dequant-dot keeps the VALU pipes busy for 0.43-0.48 of the launch: not the bound
-        for tag in ("r05", "r04"):
+        for tag in ("r06", "r05", "r04"):
             if "valu" in roofline:
                 break
-            sq_path = os.path.join(ROOT, "profiles", "%s_sq_counters_gate_up.json" % tag)
+            sq_path = os.path.join(ROOT, "profiles", "%s_sq_counters_%s.json" % (tag, "ffn_pair" if pair else "gate_up"))
             if os.path.exists(sq_path) and args.model == "7b":
                 sq = json.load(open(sq_path))
-                clock_ghz, clock_src = sample_sclk_ghz(lambda: tr.generate_ids(PROMPT_IDS, ntok))   # shader clock under this load
+                clock_ghz, clock_src = sample_sclk_ghz(lambda: tr.generate_ids(PROMPT_IDS, ntok), device=local_rank)   # shader clock under this load
+                if clock_ghz is None:
+                    roofline["valu"] = {"note": "no shader clock reading (%s): the committed SQ counters are not priced" % clock_src}
+                    break
                 busy_us = sq.get("valu_busy_cycles_per_simd", 0.0) / (clock_ghz * 1e3)
                 roofline["valu"] = {"instructions_per_launch": sq.get("SQ_INSTS_VALU"), "instructions_per_wave": sq.get("valu_instructions_per_wave"),
                                     "cycles_per_instruction": sq.get("cycles_per_valu_instruction"),
                                     "busy_cycles_per_simd": sq.get("valu_busy_cycles_per_simd"), "sclk_GHz": round(clock_ghz, 3), "sclk_source": clock_src,
                                     "busy_us": round(busy_us, 2),
                                     "busy_fraction_of_launch": round(busy_us / dom["us"], 3),
-                                    "reading": "the VALU pipes are busy for less than half of the launch: the gate/up kernel is bounded by first-data latency + "
-                                               "the x chain + the tail of its stream, not by VALU issue (DESIGN.md)",
-                                    "source": "profiles/%s_sq_counters_gate_up.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ...)" % tag}
+                                    "reading": ("the VALU pipes are busy for %.2f of the launch" % (busy_us / dom["us"])) + (": below one half the launch is bounded by first-data "
+                                               "latency, the x chain, the hand-off and the tail of its stream rather than by VALU issue (DESIGN.md)" if busy_us / dom["us"] < 0.5 else ""),
+                                    "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ...)" % os.path.basename(sq_path)}
         kernels["in_network_us"] = in_network
-        int4_bytes = sum(kb[k][1] for k in (0, 2, 3, 4))
-        int4_us = sum(kernels[kb[k][0]]["us"] for k in (0, 2, 3, 4))
+        ids4 = (10, 3, 4) if pair else (0, 2, 3, 4)
+        int4_bytes = sum(kb[k][1] for k in ids4)
+        int4_us = sum(kernels[kb[k][0]]["us"] for k in ids4)
         kernels["int4_gemv_all_per_layer"] = {"us": round(int4_us, 3), "bytes": int4_bytes, "GBps": round(int4_bytes / int4_us / 1e3, 1)}
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restating run_llama_network ------------------
@@ -403,7 +425,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.model == "7b" and ntok == 256:
         extra = {}
         tr.close()
-        for mname, n in (("7b", 2048), ("13b", 256)):
+        for mname, n in (("7b", 2048), ("13b", 256), ("13b", 2048)):
             g2 = synth.GEOMETRIES[mname]
             p2 = os.path.join(args.model_dir, "llama2_q4_synth_%s_seed20240229.bin" % mname)
             if not (os.path.exists(p2) and os.path.getsize(p2) == synth.model_bytes(g2)):
@@ -412,7 +434,9 @@ def main():
             t2.generate_ids(PROMPT_IDS, n)                       # warm + graph capture of every bin
             runs = [t2.generate_ids(PROMPT_IDS, n) for _ in range(2)]
             best = max(r[1] for r in runs)
-            gb = GB_PER_TOKEN[(mname, n)]
+            kv_dim2 = g2[0] * g2[4] // g2[3]
+            streamed2 = synth.model_bytes(g2) - 32 - g2[5] * g2[0] * 2            # every tensor but the embedding table (one row of it per token)
+            gb = GB_PER_TOKEN.get((mname, n), round((streamed2 + 2 * g2[2] * (n / 2.0 + 0.5) * kv_dim2 * 2) / 1e9, 3))
             extra["llama2_%s_n%d" % (mname, n)] = {"tokens_per_s": round(best, 1), "ms_per_token": round(1000.0 / best, 4), "GB_per_token": gb,
                                                     "frac_of_8TBps": round(best * gb / HBM_PEAK_GBS, 4)}
             if n == 2048:
@@ -421,11 +445,10 @@ def main():
                 half = min(t2.generate_ids(PROMPT_IDS, 1024)[3] for _ in range(2))
                 full = min(r[3] for r in runs)
                 tps_hi = 1024.0 / (full - half)
-                kv_dim2 = g2[0] * g2[4] // g2[3]
-                gb_hi = (3627302912 + 2 * g2[2] * 1536.5 * kv_dim2 * 2) / 1e9
+                gb_hi = (streamed2 + 2 * g2[2] * 1536.5 * kv_dim2 * 2) / 1e9
                 extra["llama2_%s_n%d" % (mname, n)]["positions_1024_2047"] = {"tokens_per_s": round(tps_hi, 1), "ms_per_token": round(1000.0 / tps_hi, 4),
                                                                               "GB_per_token": round(gb_hi, 3), "frac_of_8TBps": round(tps_hi * gb_hi / HBM_PEAK_GBS, 4)}
-            if mname == "13b":
+            if mname == "13b" and n == 256:
                 # the 13B launches by HIP events inside the eager network, like roofline.per_kernel above (gate/up and the down projection run as
                 # strips there: csrc/gemv_strip.h, gemv_strip_down.h)
                 class _C2:

@@ -225,7 +225,7 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
                              int copyLogits, Sampler* pSampler);
 
 /* 0: 1:1 kernel sequence of the reference (10 launches/layer); 1: fused kernels (rmsnorm folded into the consumer GEMV,
- * RoPE + KV write in the QKV epilogue: 5 launches/layer); 3 (default): additionally attention -> o-proj (llama2_q4.cu:320-323)
+ * RoPE + KV write in the QKV epilogue: 5 launches/layer); 3: additionally attention -> o-proj (llama2_q4.cu:320-323)
  * as ONE launch where the geometry has that form (heads of 64 / 128 / 256, multi-head or grouped-query) and every block of the
  * launch fits the stream's CUs at once: the o-proj blocks pull their weights while the heads work and take the heads' output
  * inside the launch (bounded waits, q4_handoff_status), 4 launches/layer. 2 selects 1 (round 2's QKV -> attention -> o-proj
@@ -233,8 +233,8 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * attention output's positions (below bin 512 the fused launch's attention role takes 16 positions per wave instruction of a
  * 64-byte V slice, the stand-alone kernel 4; 8 waves instead of 16): logits agree within the model's tolerance in every bin, not
  * bit for bit. After a timed-out hand-off the library runs level 1 for the next 16 sequences (32, 64, ... after further
- * time-outs), then tries level 3 again; q4_set_fusion(3) re-arms it at once. Resets captured graphs.
- * 4: additionally the FFN half of a layer (rmsnorm + gate/up + SiLU + down projection + residual add, llama2_q4.cu:326-332) as ONE
+ * time-outs), then tries the level it had again; q4_set_fusion(level) re-arms it at once. Resets captured graphs.
+ * 4 (default): additionally the FFN half of a layer (rmsnorm + gate/up + SiLU + down projection + residual add, llama2_q4.cu:326-332) as ONE
  * launch where q4_ffn_pair_covers says so (Llama-2-7B's dim / hidden_dim): one block per CU computes its slice of hb, hands it to every
  * other CU inside the launch and multiplies its columns of the down projection, whose weights it has meanwhile streamed into LDS;
  * 3 launches/layer, bit-identical to levels 1 / 3 (same bounded waits, same fallback after a time-out). */
@@ -283,6 +283,9 @@ int q4_shared_pos(const RunState* s);
  * A loop built on q4_run_transformer should call it wherever it synchronises. q4_handoff_timeouts: incidents so far. */
 int q4_handoff_status(const RunState* s);
 int q4_handoff_timeouts(void);
+/* Diagnostic: duration of the K / V stream per context position, in ticks of 10 ns, as q4_build_transformer measured it for this model on this device
+ * (the split-context attention -> o-proj launch prices its held-back weight requests from it); 0: not measured (seq_len < 1024). */
+double q4_kv_stream_price(const RunState* s);
 int q4_shared_token(const RunState* s, int index);
 /* parity dumps: synchronise, then copy fp16 logits / a KV row / the residual to the host */
 int q4_get_logits(const Transformer* t, q4_half* host_out);

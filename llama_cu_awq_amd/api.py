@@ -58,7 +58,7 @@ SYMBOLS = [
     "build_sampler", "destroy_sampler", "random_u32", "random_f32", "q4_sample", "q4_build_transformer",
     "q4_free_transformer", "q4_set_quiet", "q4_transformer_new", "q4_transformer_delete", "q4_transformer_config",
     "q4_transformer_state", "q4_transformer_weights", "q4_sampler_new", "q4_sampler_delete", "q4_reset_sequence",
-    "q4_shared_pos", "q4_handoff_status", "q4_handoff_timeouts", "q4_shared_token", "q4_get_logits", "q4_get_kv_row", "q4_get_logits_array", "q4_generate",
+    "q4_shared_pos", "q4_handoff_status", "q4_handoff_timeouts", "q4_kv_stream_price", "q4_shared_token", "q4_get_logits", "q4_get_kv_row", "q4_get_logits_array", "q4_generate",
     "q4_generate_ids", "q4_chat", "q4_softmax_f32", "compute_perplexity", "q4_get_dataset_perplexity",
     "q4_parse_dataset_and_compute_perplexity", "q4_perplexity_ids", "q4_tokenizer_new", "q4_tokenizer_delete",
     "q4_tokenizer_encode", "q4_tokenizer_decode", "q4_tokenizer_max_token_length", "q4_main", "q4_parse_args",
@@ -117,6 +117,9 @@ def lib():
     L.q4_run_transformer.argtypes = [i, C.POINTER(Config), C.POINTER(RunState), C.POINTER(TransformerWeights), i, vp]
     L.q4_set_fusion.argtypes = [i]
     L.q4_set_fusion.restype = None
+    if hasattr(L, "q4_kv_stream_price"):
+        L.q4_kv_stream_price.restype = C.c_double
+        L.q4_kv_stream_price.argtypes = [vp]
     if hasattr(L, "q4_ffn_pair_covers"):           # (older builds under tools/ab.py do not have it)
         L.q4_ffn_pair_covers.argtypes = [i, i]
     L.q4_set_use_graphs.argtypes = [i]

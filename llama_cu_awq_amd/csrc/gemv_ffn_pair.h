@@ -29,6 +29,7 @@ struct FfnPairArgs {
     int Kd, Nd, pw4, pzh, sh, ku;   // down projection: K = hidden, N = dim, packed geometry, uint4 units per k-part (gemv_q4.h, KS = 2)
     unsigned dbase, drem;      // its output columns per block
     unsigned pre;              // gather mode: bit 0 = the first pass with plain loads, bit 1 = ... once the wave's own down pieces have landed
+    unsigned tag_add;          // 0 in the network. bench launches without a QKV launch in between (q4_bench.hip) make their tags distinct with it
     int mute;                  // profiling build: the blocks do not publish (a real time-out, tests/prof_cases.py)
     unsigned long long* dbg;   // profiling build: [block][64] wall-clock stamps
 };
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     block_barrier_lds();                               // barrier A: the block's gate/up totals are in LDS, its rings are dead
 
     // ---- the seam
-    const unsigned tag = ee[1], dead = ee[0];
+    const unsigned tag = ee[1] + p.tag_add, dead = ee[0];
     u32x4 ha = {0u, 0u, 0u, 0u}, hb2 = {0u, 0u, 0u, 0u};    // this thread's chunks of hb (8 halves each)
     const unsigned gt = tid - 64u;                          // gather thread (waves 1 .. 15): chunks gt and gt + 960
     const unsigned nch2 = (unsigned)p.Kd >> 3;

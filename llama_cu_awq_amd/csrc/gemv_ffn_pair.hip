@@ -34,7 +34,7 @@ int ffn_pair_prepare() {
 }
 
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word) {
+                    unsigned* sync, size_t gran_word, unsigned tag_add) {
     if (!rms_w || !sync || !ffn_pair_covers(dim, hidden)) return Q4_ERR_UNSUPPORTED_SIZE;
     { const int rc = ffn_pair_prepare(); if (rc) return rc; }
     GemvArgs a = {};
@@ -53,6 +53,7 @@ int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight
     p.ku = (divUp(g.pw4, 2) + 3) & ~3;                       // whole quantisation groups per k-part (gemv_plain.hip)
     p.dbase = (unsigned)dim / nb; p.drem = (unsigned)dim % nb;
     p.pre = (unsigned)g_fp_pre;
+    p.tag_add = tag_add;
     const unsigned pairs = (unsigned)hidden / 2u;
 #ifdef Q4_PROFILING
     if (g_fp_mute > 0) { p.mute = 1; g_fp_mute--; }

@@ -355,7 +355,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
     }
 #define Q4_ISSUE_ANY(s) { if (HALF && (s) == SLOTS - 1) Q4_ISSUE_HALF() else Q4_ISSUE_SLOT(s) }
     if (ROLE == ROLE_CONSUMER) {   // held back while the producers' stream needs the memory system for itself (layer_attn.h)
-        if (ho.hold_until != 0ull) while (wall_clock64() < ho.hold_until) __builtin_amdgcn_s_sleep(4);
+        if (ho.hold_until != 0ull && ho.dead == 0u) while (wall_clock64() < ho.hold_until) __builtin_amdgcn_s_sleep(4);   // (a launch queued behind a time-out holds nothing back)
     }
 #pragma unroll
     for (int s = 0; s < PRE; s++) Q4_ISSUE_ANY(s)

@@ -14,11 +14,13 @@ static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->z
 int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention blocks of the next n launches do not publish
 int g_ao_vslice = 1;  // below the split-context bins: head_size / 32 attention blocks per head, one 64-byte V slice each (0: one block)
 int g_att_ring = 0;   // profiling knob 14: the split-context attention role takes its K / V rows on LDS-DMA rings (same bits, same speed: DESIGN.md)
-// split-context bins: the o-proj role requests its weights after this share of the K / V stream's estimated duration (0: at entry). -1 = the measured
-// optimum per bin (tools/lab/sweep_attn_hold.py, 7B, ms per token inside the bin, hold 0 / 100 / 140 / 180 %: bin 512 1.0933 / 1.0777 / 1.0710 / 1.0807,
-// bin 1024 1.1229 / 1.1120 / 1.1255 / 1.1334, bin 2048 1.1925 / 1.1812 / 1.1979 / 1.2147)
+// split-context bins: the o-proj role requests its weights after this share of the K / V stream's duration (0: at entry). The duration is priced per context
+// position from the slope q4_build_transformer measures with the stand-alone split-context attention launch (q4_runtime.hip measure_kv_price: 2.15 ns per
+// position at Llama-2-7B on MI355X = 7.6 TB/s; the fused launch's own stream -- rows, records and then the held-back weights -- runs 1.3 x as long, which is
+// why the optimum sits above 100 %). -1 = the measured optimum per bin (tools/lab/sweep_attn_hold.py, 7B, ms per token inside the bin at 0 / 130 / 180 / 230 %
+// of that slope: bin 512 1.0933 / 1.0777 / 1.0710 / 1.0807, bin 1024 1.1229 / 1.1120 / 1.1255 / 1.1334, bin 2048 1.1925 / 1.1812 / 1.1979 / 1.2147)
 int g_ao_hold_pct = -1;
-static int ao_hold_pct(int seq_len_bin) { return g_ao_hold_pct >= 0 ? g_ao_hold_pct : seq_len_bin <= 512 ? 140 : 100; }
+static int ao_hold_pct(int seq_len_bin) { return g_ao_hold_pct >= 0 ? g_ao_hold_pct : seq_len_bin <= 512 ? 180 : 130; }
 int g_ao_guard = 1;   // profiling build: q4_set_gemv_early(8, 0) admits grids larger than the resident capacity (forward-progress tests)
 
 // CUs the launch stream may use: all of the device, or the bits of its CU mask (hipExtStreamCreateWithCUMask)
@@ -42,6 +44,13 @@ int stream_cu_count() {
     cache[g_stream] = n;
     return n;
 }
+
+// 10 ns ticks per context position of a model's K / V stream, by its hand-off words (q4_runtime.hip measures at build, forgets at free)
+static std::map<const unsigned*, double>& kv_price() { static std::map<const unsigned*, double> m; return m; }
+void attention_set_kv_price(const unsigned* sync, double ticks_per_pos) {
+    if (ticks_per_pos > 0.0) kv_price()[sync] = ticks_per_pos; else kv_price().erase(sync);
+}
+double attention_get_kv_price(const unsigned* sync) { auto it = kv_price().find(sync); return it == kv_price().end() ? 0.0 : it->second; }
 
 struct AoShape { int att, slots_kind, slots, nsp; AttOprojLaunch launch; };
 
@@ -131,9 +140,12 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     // 34 KB per block). Llama-2-13B's 160 blocks pull 85 KB each: held back they end the launch later (tools/lab/sweep_knob.py 13b 15 0,-1: bin 2048
     // 2.0285 -> 2.1179 ms per token), so they request at entry as before
     const size_t oproj_block_bytes = ((size_t)g.pw4 * 16 + (size_t)g.pzh * 4 + (size_t)g.sh * 2) * (size_t)dim / a.no;
-    if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0 && (g_ao_hold_pct >= 0 || oproj_block_bytes <= 48 * 1024)) {
-        // K and V rows of one position: 2 x kv_dim halves; the stream moves at ~5.9 TB/s (measured, tools/lab/timeline_split.py); 10 ns ticks, Q16
-        const double ticks_per_pos = (4.0 * kv_dim) / 5.9e12 * 1e8;
+    // ... and only on a stream that may use every CU: the price below was measured there (a CU-masked stream draws its rows at another rate)
+    if (att_is_split(s.att) && ao_hold_pct(seq_len_bin) > 0 && (g_ao_hold_pct >= 0 || oproj_block_bytes <= 48 * 1024) && stream_cu_count() == cu_count()) {
+        // time per context position of the K / V stream, in 10 ns ticks, Q16: measured for THIS model on THIS device when it was built
+        // (q4_runtime.hip measure_kv_price); without a measurement (contexts below 1024) priced from the rows' bytes at the 7.6 TB/s measured on MI355X
+        auto it = kv_price().find(sync);
+        const double ticks_per_pos = it != kv_price().end() && it->second > 0.0 ? it->second : (4.0 * kv_dim) / 7.6e12 * 1e8;
         a.hold_q16 = (unsigned)(ticks_per_pos * 65536.0 * ao_hold_pct(seq_len_bin) / 100.0);
     }
 #ifdef Q4_PROFILING

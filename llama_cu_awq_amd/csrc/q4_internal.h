@@ -94,6 +94,8 @@ int attention_oproj_form(int dim, int kv_dim, int head_size, int n_heads, int se
 int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_half* key_cache, const q4_half* value_cache,
                            const QWeight* wo, int dim, int kv_dim, int n_heads, const int* pPos, int seq_len_bin, unsigned* sync,
                            float* scratch, size_t scratch_bytes, int split_min, int split_chunk);
+void attention_set_kv_price(const unsigned* sync, double ticks_per_pos);   // layer_attn.hip: what the split-context launch's hold-back is priced from
+double attention_get_kv_price(const unsigned* sync);
 extern int g_att_chunk;
 extern int g_att_split_min;
 extern int g_ao_guard;
@@ -154,7 +156,8 @@ bool ffn_pair_covers(int dim, int hidden);
 size_t ffn_pair_sync_words(int hidden);
 int ffn_pair_prepare();     // gemv_ffn_pair.hip: LDS opt-in, outside any stream capture
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word);
+                    unsigned* sync, size_t gran_word, unsigned tag_add = 0);
+unsigned* sync_words_of_state(const RunState* s);   // q4_runtime.hip: the model's hand-off words, or null
 extern int g_fp_pre, g_fp_mute, g_fp_nt;
 
 }  // namespace q4

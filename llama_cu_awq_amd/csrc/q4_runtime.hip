@@ -14,12 +14,12 @@
 namespace q4 {
 
 hipStream_t g_stream = nullptr;
-int g_fusion = 3;
+int g_fusion = 4;
 int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
-static int g_rearm_after = 0;          // > 0: sequences left at fusion level 1 before level 3 is tried again (after a timed-out hand-off)
-static int g_rearm_level = 3;          // the fusion level that comes back when the probation ends
+static int g_rearm_after = 0;          // > 0: sequences left at fusion level 1 before the level in force is tried again (after a timed-out hand-off)
+static int g_rearm_level = 4;          // the fusion level that comes back when the probation ends
 static int g_rearm_backoff = 16;       // sequences to sit out after the next time-out: doubles every time, so a box that keeps stalling settles at level 1
 static int g_handoff_timeouts = 0;     // timed-out in-launch waits seen by q4_handoff_status since the library was loaded
 char g_last_error[512] = "";
@@ -61,6 +61,7 @@ static unsigned* sync_words_of(const RunState* s) {
 // sequence that reached the same (position, layer) used to re-create the first one's tag and could merge its stale records).
 // Cleared: arrival counters and granules, and the error word when asked. Past 2^31 launches (days of decoding) the epoch does
 // start over, together with every buffer that holds tags.
+unsigned* sync_words_of_state(const RunState* s) { return sync_words_of(s); }
 static int clear_handoff_state(const RunState* s, bool error_too) {
     unsigned* sync = sync_words_of(s);
     auto it = g_sync_words.find(s);
@@ -318,6 +319,53 @@ static int upload_qweight(QWeight* w, FILE* fp, int height, int width, void* scr
     return Q4_OK;
 }
 
+// The split-context attention -> o-proj launch holds its o-proj role's weight requests back until the K / V stream of the context is about to end
+// (layer_attn.h). What it needs is the stream's duration per context position ON THIS DEVICE, for THIS model's rows: measured here, once per model, with the
+// product's own split-context attention launch at two context lengths (dispatch timestamps on the launch stream; the slope is the price, the fixed part of
+// a launch drops out) -- instead of a constant measured on one box in round 5. A few hundred microseconds of build time; the run
+// state is all zeros at this point and stays so (the launch writes xb and its scratch records only).
+static void measure_kv_price(const Config* p, RunState* s, unsigned* sync) {
+    const int head_size = p->dim / p->n_heads;
+    const int kv_dim = (p->dim * p->n_kv_heads) / p->n_heads;
+    const int n2 = p->seq_len < 2048 ? p->seq_len : 2048, n1 = n2 / 2;
+    if (n1 < 512 || p->n_heads > SYNC_MAX_HEADS || !(head_size == 64 || head_size == 128 || head_size == 256) || !s->att || g_stream == nullptr) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
+    double t[2] = {0.0, 0.0};
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++) {
+        const int n = k ? n2 : n1;
+        const int last = n - 1;
+        ok = hipMemcpyAsync(s->pos, &last, sizeof(int), hipMemcpyHostToDevice, g_stream) == hipSuccess && hipStreamSynchronize(g_stream) == hipSuccess;
+        double best = 1e30;
+        for (int rep = 0; rep < 12 && ok; rep++) {       // the minimum of a dozen launches: the stream's own time, not a neighbour's
+            // every launch on ANOTHER layer's rows (the token loop comes back to a layer after all the others: its rows come from HBM, while a
+            // repeated read of one layer's 33 MB would come out of the 256 MB Infinity Cache at twice the rate)
+            const size_t loff = (size_t)((rep * 7 + k * 3) % p->n_layers) * p->seq_len * kv_dim;
+            g_ev_start = e0; g_ev_stop = e1;
+            const int rc = launch_attention(s->xb, s->q, s->key_cache + loff, s->value_cache + loff, p->n_heads, head_size, p->n_heads / p->n_kv_heads, n, s->pos,
+                                            (float*)s->att, att_buffer_bytes(p), p->n_heads <= SYNC_MAX_HEADS ? sync + SYNC_ARRIVE : nullptr);   // ONE launch: merged by each head's last block (the counters re-arm themselves)
+            g_ev_start = g_ev_stop = nullptr;
+            float ms = 0.f;
+            ok = rc == Q4_OK && hipStreamSynchronize(g_stream) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (ok && rep >= 2 && ms > 0.f && ms < best) best = ms;
+        }
+        t[k] = best;
+    }
+    const int zero = 0;
+    (void)hipMemcpyAsync(s->pos, &zero, sizeof(int), hipMemcpyHostToDevice, g_stream);
+    (void)hipMemsetAsync(s->xb, 0, (size_t)p->dim * sizeof(q4_half), g_stream);
+    (void)hipStreamSynchronize(g_stream);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (!ok) { (void)hipGetLastError(); if (getenv("Q4_DEBUG_KV")) fprintf(stderr, "llama2_q4: kv price: measurement failed\n"); return; }
+    const double ticks_per_pos = (t[1] - t[0]) * 1e-3 / (double)(n2 - n1) * 1e8;      // ms -> s -> 10 ns ticks
+    // sanity: between a third of and three times the rows' bytes at 7.6 TB/s (what MI355X measures) -- outside that the measurement was disturbed and
+    // the constant stands in
+    const double nominal = (4.0 * kv_dim) / 7.6e12 * 1e8;
+    if (getenv("Q4_DEBUG_KV")) fprintf(stderr, "llama2_q4: kv price: %d positions %.3f us, %d positions %.3f us -> %.4f ticks / position (nominal %.4f)\n", n1, t[0] * 1e3, n2, t[1] * 1e3, ticks_per_pos, nominal);
+    if (ticks_per_pos > nominal / 3.0 && ticks_per_pos < nominal * 3.0) attention_set_kv_price(sync, ticks_per_pos);
+}
+
 int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perplexity) {
     memset(t, 0, sizeof(*t));
     FILE* file = fopen(checkpoint_path, "rb");
@@ -459,6 +507,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
         g_sync_by_state[&t->state] = slabs.sync;
         g_sync_words[&t->state] = sync_words;
         g_att_bytes[&t->state] = att_buffer_bytes(p);
+        measure_kv_price(p, &t->state, slabs.sync);
     } else {
         (void)hipGetLastError();    // no hand-off words: the network runs its five-launch sequence
     }
@@ -477,7 +526,7 @@ void q4_free_transformer(Transformer* t) {                                      
         if (it->second.shared) hipHostFree(it->second.shared);
         if (it->second.logits_array) hipFree(it->second.logits_array);
         if (it->second.rope_table) hipFree(it->second.rope_table);
-        if (it->second.sync) hipFree(it->second.sync);
+        if (it->second.sync) { attention_set_kv_price(it->second.sync, 0.0); hipFree(it->second.sync); }
         g_rope_by_state.erase(&t->state);
         g_sync_by_state.erase(&t->state);
         g_sync_words.erase(&t->state);
@@ -487,6 +536,8 @@ void q4_free_transformer(Transformer* t) {                                      
     free(t->weights.layers);
     memset(t, 0, sizeof(*t));
 }
+
+double q4_kv_stream_price(const RunState* s) { unsigned* sync = sync_words_of(s); return sync ? attention_get_kv_price(sync) : 0.0; }
 
 Transformer* q4_transformer_new(const char* checkpoint_path, int perplexity, int* status) {
     Transformer* t = (Transformer*)calloc(1, sizeof(Transformer));
@@ -891,12 +942,12 @@ int q4_steps_that_fit(int pos, int num_prompt_tokens, int steps, const Config* p
     if (graph_bin(pos + 1, p, &b0) != graph_bin(pos + k, p, &b1)) return 1;
     return k;
 }
-// The in-launch hand-offs of fusion level 3 (attention -> o-proj, layer_attn.h) spin for a bounded time; a spin that ran out
+// The in-launch hand-offs of fusion levels 3 and 4 (attention -> o-proj, layer_attn.h; the FFN pair launch, gemv_ffn_pair.h) spin for a bounded time; a spin that ran out
 // sets the model's error word: everything computed since is invalid. Synchronises the stream and reports it ONCE: the word,
 // the counters and the granules are cleared (the epoch keeps counting: tags never repeat), and the library drops to fusion
 // level 1 (no in-launch waits), so the caller can simply redo the sequence -- the token loops of this library do exactly that.
-// Level 3 comes back by itself after 16 sequences (q4_reset_sequence counts them; 32, 64, ... after further time-outs) or at
-// once with q4_set_fusion(3).
+// The level in force comes back by itself after 16 sequences (q4_reset_sequence counts them; 32, 64, ... after further time-outs) or at
+// once with q4_set_fusion(level).
 int q4_handoff_status(const RunState* s) {
     Q4_HIP(hipStreamSynchronize(g_stream));
     unsigned* sync = sync_words_of(s);
@@ -914,7 +965,7 @@ int q4_handoff_status(const RunState* s) {
             if (g_rearm_backoff < (1 << 20)) g_rearm_backoff *= 2;
             q4_reset_graphs();
         }
-        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level 3); state cleared, continuing at fusion level 1 for the next %d sequences", g_rearm_after);
+        snprintf(g_last_error, sizeof(g_last_error), "an in-launch hand-off timed out (fusion level %d); state cleared, continuing at fusion level 1 for the next %d sequences", g_rearm_level, g_rearm_after);
         if (!g_quiet) fprintf(stderr, "llama2_q4: %s\n", g_last_error);
         return Q4_ERR_HIP;
     }

@@ -285,7 +285,7 @@ def test_a_timed_out_handoff_is_reported_once_and_the_sequence_is_redone_at_leve
         for i in range(30):
             assert np.array_equal(t.generate_ids(prompt, 12)[0], want[:13]) and L.q4_get_fusion() == 1, i
         assert np.array_equal(t.generate_ids(prompt, 40)[0][:12], want[:12])
-        assert L.q4_get_fusion() == 3 and L.q4_handoff_timeouts() == 2
+        assert L.q4_get_fusion() == q4.DEFAULT_FUSION and L.q4_handoff_timeouts() == 2
         t.close()
     finally:
         L.q4_set_gemv_early(9, 0)

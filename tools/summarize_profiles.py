@@ -63,6 +63,8 @@ def algorithmic(kernel, model, ntok):
     kernel = kernel[4:] if kernel.startswith("q4::") else kernel
     if kernel.startswith("gemv_q4_kernel<2") or kernel.startswith("ffn_engine_kernel") or kernel.startswith("ffn_strip_kernel") or kernel.startswith("ffn_strip_pair_kernel"):
         return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
+    if kernel.startswith("ffn_pair_kernel"):     # fusion level 4: gate/up + down in one launch (bench.py kernel_bytes id 10); the hb hand-off inside the launch is not algorithmic
+        return 2 * qweight_bytes(d, h) + qweight_bytes(h, d) + 4 * d * 2 + h * 2
     if kernel.startswith("gemv_q4_kernel<1"):
         return 3 * qweight_bytes(d, d) + 2 * d * 2 + 3 * d * 2
     if kernel.startswith("gemv_q4_kernel<0") or kernel.startswith("down_strip_kernel"):
@@ -116,8 +118,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
     print(model, ntok, json.dumps(per)[:600])
 if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from here
     for k, e in traffic["7b_n256"].items():
-        if k.replace("q4::", "").startswith(("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")):   # the fused gate/up launch in whatever form the product runs it
+        if k.replace("q4::", "").startswith(("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")) and "0" not in traffic:   # the fused gate/up launch in whatever form the product runs it
             traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
+                            "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
+        if k.replace("q4::", "").startswith("ffn_pair_kernel"):      # ... or, at fusion level 4, the FFN pair launch: the decode path's dominant launch
+            traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_down_accum_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
 traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
                    "product's own launch sequence (tools/prof_decode.py). FETCH_SIZE on gfx950 tallies the 128-B requests of 16 B/lane "
@@ -132,7 +137,7 @@ sq = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(src, "pmc_k0_sq", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(n in r["Kernel_Name"] for n in ("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")):
+        if any(n in r["Kernel_Name"] for n in ("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel", "ffn_pair_kernel")):
             sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {"kernel": short(r["Kernel_Name"]), "vgpr": int(r["VGPR_Count"]), "workgroup": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
 if sq:
@@ -147,5 +152,6 @@ if sq:
     out["note"] = ("rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES over "
                    "tools/prof_kernel.py 0 32 (the fused gate/up launch over the ring of the layers' weights); SQ_ACTIVE_INST_VALU counts quad-cycles "
                    "summed over the chip's 1024 SIMDs (MI355X_MICROARCH.md, per-instruction constants)")
-    json.dump(out, open(os.path.join(dst, "%s_sq_counters_gate_up.json" % tag), "w"), indent=1)
-    print("gate/up SQ counters:", json.dumps(out)[:400])
+    # (the FFN pair launch, where the round's collection timed kernel 10: the decode path's dominant launch at fusion level 4)
+    json.dump(out, open(os.path.join(dst, "%s_sq_counters_%s.json" % (tag, "ffn_pair" if "ffn_pair_kernel" in out.get("kernel", "") else "gate_up")), "w"), indent=1)
+    print("SQ counters:", json.dumps(out)[:400])
