@@ -6,7 +6,6 @@ int launch_gemv_qkv(const GemvArgs& a, int cols, int waves) {
         return a.rms_w ? launch_one<MODE_QKV, S, 4, true>(a, waves) : launch_one<MODE_QKV, S, 4, false>(a, waves); }
     const int slots = pick_slots(a.nslots);
     (void)cols;   // 4 columns (two RoPE pairs) per wave
-    if (g_lab.qkv_covers && g_lab.qkv_covers(a)) return g_lab.qkv_launch(a);   // (null in the shipped library: q4_internal.h)
     if (slots == 3 && a.nslots == 3 && half_tail(a))
         return a.rms_w ? launch_one<MODE_QKV, 3, 4, true, 0, 1, true>(a, waves) : launch_one<MODE_QKV, 3, 4, false, 0, 1, true>(a, waves);
     Q4_CASE(2) Q4_CASE(3) Q4_CASE(4) Q4_CASE(6) Q4_CASE(7) Q4_CASE(8)

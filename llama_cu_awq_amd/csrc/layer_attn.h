@@ -45,35 +45,12 @@ struct AttOprojArgs {
 // ATT 0 / 1: one block per head, 128 / 256 positions per register-resident pass; 2 / 3 / 4: one block per (head, 128 / 256 / 64
 // positions), merged by each head's first chunk block; 5 / 6: 0 / 1 with head_size / 32 blocks per head, each taking one 64-byte
 // slice of the V rows (attention.h, VS; the default below bin 512). LPR = lanes per cache row of a head (head_size / 8).
-// 7 / 8 / 9 (laboratory, profiling library only): the split-context forms 2 / 3 / 4 with their K / V rows on LDS-DMA rings (exp/attention_ring.h; same bits,
-// measured level).
-#ifndef Q4_ATT_RING
-#define Q4_ATT_RING 4                // 1 KiB pieces per wave of the ring forms (tools/lab/build_ring_variants.sh builds other depths for the A/B)
-#endif
-// block LDS of the launch: the default 64 KiB without an opt-in; ring depths of 8 pieces and more (A/B builds) opt in where they are first asked for
-constexpr size_t AO_LDS_MAX = Q4_ATT_RING > 7 ? 160 * 1024 : 64 * 1024;
-constexpr bool att_is_split(int att) { return (att >= 2 && att <= 4) || (att >= 7 && att <= 9); }
-constexpr int att_ring(int att) { return att >= 7 && att <= 9 ? Q4_ATT_RING : 0; }
-template <int ATT> struct AttLoad { using type = KvInRegisters; };
-#ifdef Q4_PROFILING
-}  // namespace q4
-#include "exp/attention_ring.h"
-namespace q4 {
-template <> struct AttLoad<7> { using type = KvOnRings<Q4_ATT_RING>; };
-template <> struct AttLoad<8> { using type = KvOnRings<Q4_ATT_RING>; };
-template <> struct AttLoad<9> { using type = KvOnRings<Q4_ATT_RING>; };
-#define Q4_AO_LAB_CASES(LPR)                                                                                                         \
-    case 7: return go(attention_oproj_kernel<2, false, 7, LPR>); case 8: return go(attention_oproj_kernel<2, false, 8, LPR>);        \
-    case 9: return go(attention_oproj_kernel<2, false, 9, LPR>); case 23: return go(attention_oproj_kernel<3, true, 7, LPR>);        \
-    case 24: return go(attention_oproj_kernel<3, true, 8, LPR>); case 25: return go(attention_oproj_kernel<3, true, 9, LPR>);        \
-    case 39: return go(attention_oproj_kernel<4, false, 7, LPR>); case 40: return go(attention_oproj_kernel<4, false, 8, LPR>);      \
-    case 41: return go(attention_oproj_kernel<4, false, 9, LPR>);
-#else
-#define Q4_AO_LAB_CASES(LPR)
-#endif
+// (Round 5's K / V rows on LDS-DMA rings -- forms 7 / 8 / 9 -- measured level and left the tree in round 6: EXPERIMENTS.md #29.)
+constexpr size_t AO_LDS_MAX = 64 * 1024;     // block LDS of the launch: the default 64 KiB, no opt-in
+constexpr bool att_is_split(int att) { return att >= 2 && att <= 4; }
 template <int LPR, int ATT>
 struct AttShape {
-    static constexpr int CHUNK = ATT == 4 || ATT == 9 ? 64 : ATT == 0 || ATT == 2 || ATT == 5 || ATT == 7 ? 128 : 256;
+    static constexpr int CHUNK = ATT == 4 ? 64 : ATT == 0 || ATT == 2 || ATT == 5 ? 128 : 256;
     static constexpr int U = CHUNK / (LA_WAVES * (64 / LPR));
     static constexpr int VS = ATT == 5 || ATT == 6 ? LPR / 4 : 1;
     static constexpr int LB = ATT == 1 || ATT == 6 ? 128 : 0;   // forms entered above position 127 only (bins > 128)
@@ -120,7 +97,7 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
         ho.pub = g_att;
         if constexpr (ATT <= 1) attention_body<LPR, U, NW, 2, false, 1, AttShape<LPR, ATT>::LB>(a.att, (int)b, ho);
         else if constexpr (ATT == 5 || ATT == 6) attention_body<LPR, U, NW, 2, false, AttShape<LPR, ATT>::VS, AttShape<LPR, ATT>::LB>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
-        else attention_split_body<LPR, U, true, NW, typename AttLoad<ATT>::type>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
+        else attention_split_body<LPR, U, true, NW>(a.split, (int)(b % a.nheads), (int)(b / a.nheads), (int)(a.natt / a.nheads), ho);
     } else {
         const unsigned j = b - a.natt;
         if constexpr (att_is_split(ATT)) {
@@ -187,7 +164,6 @@ int launch_attention_oproj_h256(int slots_kind, int att, dim3 grid, dim3 block, 
             case 36: return go(attention_oproj_kernel<4, false, 4, LPR>);                                                 \
             case 37: return go(attention_oproj_kernel<4, false, 5, LPR>);                                                 \
             case 38: return go(attention_oproj_kernel<4, false, 6, LPR>);                                                 \
-            Q4_AO_LAB_CASES(LPR)                                                                                          \
         }                                                                                                                 \
         return Q4_ERR_UNSUPPORTED_SIZE;                                                                                   \
     }

@@ -13,7 +13,6 @@ static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->z
 
 int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention blocks of the next n launches do not publish
 int g_ao_vslice = 1;  // below the split-context bins: head_size / 32 attention blocks per head, one 64-byte V slice each (0: one block)
-int g_att_ring = 0;   // profiling knob 14: the split-context attention role takes its K / V rows on LDS-DMA rings (same bits, same speed: DESIGN.md)
 // split-context bins: the o-proj role requests its weights after this share of the K / V stream's duration (0: at entry). The duration is priced per context
 // position from the slope q4_build_transformer measures with the stand-alone split-context attention launch (q4_runtime.hip measure_kv_price: 2.15 ns per
 // position at Llama-2-7B on MI355X = 7.6 TB/s; the fused launch's own stream -- rows, records and then the held-back weights -- runs 1.3 x as long, which is
@@ -75,7 +74,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
     const int nsp = divUp(seq_len_bin, chunk);
     const bool split = seq_len_bin >= split_min && have_scratch && n_heads <= SYNC_MAX_HEADS &&
                        (size_t)n_heads * nsp * (head_size + ATT_REC_PAD) * sizeof(u32x2v) <= scratch_bytes;   // records as {float, tag} granules
-    if (split) { s.att = (chunk == 64 ? 4 : chunk == 128 ? 2 : 3) + (g_att_ring ? 5 : 0); s.nsp = nsp; return s; }   // (7 / 8 / 9: K / V rows on LDS-DMA rings)
+    if (split) { s.att = chunk == 64 ? 4 : chunk == 128 ? 2 : 3; s.nsp = nsp; return s; }
     if ((size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4 > 64 * 1024) return s;
     s.att = seq_len_bin <= 128 ? 0 : 1;
     // (only where the bin is one register-resident group of the role, <= 256 positions: a model whose scratch does not hold
@@ -86,7 +85,7 @@ static AoShape ao_shape(int dim, int kv_dim, int head_size, int n_heads, int seq
 
 static size_t ao_smem(const AoShape& s, int head_size, int seq_len_bin) {
     const size_t smem_gemv = (size_t)s.slots * 256 * 16 + (size_t)s.slots * 512 + (size_t)s.slots * 256 * 4 + 16;
-    const size_t smem_att = att_is_split(s.att) ? att_split_lds_bytes(LA_WAVES, head_size, att_ring(s.att)) : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
+    const size_t smem_att = att_is_split(s.att) ? att_split_lds_bytes(LA_WAVES, head_size, 0) : (size_t)(32 + LA_WAVES * head_size + seq_len_bin) * 4;
     return smem_gemv > smem_att ? smem_gemv : smem_att;
 }
 

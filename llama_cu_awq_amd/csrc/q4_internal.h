@@ -100,7 +100,6 @@ extern int g_att_chunk;
 extern int g_att_split_min;
 extern int g_ao_guard;
 extern int g_ao_vslice;
-extern int g_att_ring;
 extern int g_ao_hold_pct;
 extern int g_multi_steps;
 // Which form of the int4 GEMV launches run. The shipped library only ever holds GEMV_PRODUCT; the profiling library's knob 11
@@ -108,39 +107,25 @@ extern int g_multi_steps;
 enum GemvForm {
     GEMV_WAVE_OWNED = -1,             // gemv_q4_kernel everywhere (no strips)
     GEMV_PRODUCT = 0,                 // strips where they measure faster (gemv_strip.h, gemv_strip_down.h, gemv_strip_cls.h), wave-owned kernels elsewhere
-    GEMV_ENGINE_LAG1 = 1, GEMV_ENGINE_LAG2 = 2, GEMV_ENGINE_LAG3 = 3,     // exp/ffn_engine.hip: gate/up as a loader / consumer engine, fills known landed LAG behind
-    GEMV_ENGINE_LAG1_PF = 5, GEMV_ENGINE_LAG2_PF = 6,                     // ... with the consumers' next-slot prefetch
-    GEMV_STRIPS_EVERYWHERE = 8,       // every strips form wherever its shape is covered (incl. the 13B q/k/v strips of exp/qkv_strip.h)
+    GEMV_STRIPS_EVERYWHERE = 8,       // every strips form wherever its shape is covered
     GEMV_STRIPS_D4 = 9, GEMV_STRIPS_D8 = 10,                              // exp/ffn_strip_variants.h: ring depth 4 / 8
     GEMV_STRIPS_PACED_D4 = 12, GEMV_STRIPS_PACED_D8 = 13, GEMV_STRIPS_PACED_D8_ROTATED = 14,   // ... two pieces in flight whatever the depth
     GEMV_PRODUCT_NO_DOWN_STRIPS = 15, // the product's gate/up and classifier choices with the K-split kernel for every down projection
     GEMV_K5120_COLUMN_UNITS = 19,     // the product with K = 5120 gate/up strips on column units instead of pair units
 };
 extern int g_gemv_form;     // gemv_ffn_strip.hip
-// Laboratory hooks: all null in libllama2_q4.so. libllama2_q4_prof.so also links csrc/exp/*.hip, whose static initialisers register the
-// experiment forms here (loader / consumer engine, strips variants, gate/up ablations, q/k/v strips, the sampler-epilogue classifier);
-// the product's dispatchers ask a registered hook first. No experiment code is compiled into, or reachable from, the shipped library.
+// Laboratory hooks: all null in libllama2_q4.so. libllama2_q4_prof.so also links csrc/exp/lab.hip, whose static initialiser registers the
+// experiment forms that are kept for A/B (gate/up strips variants and their stamped build, gate/up ablations); the product's dispatcher asks a
+// registered hook first. No experiment code is compiled into, or reachable from, the shipped library. (Round 6 removed the forms with a conclusive
+// negative -- loader / consumer engine, q/k/v strips, the sampler-epilogue classifier, K / V rings: EXPERIMENTS.md keeps their records, git their code.)
 struct GemvArgs;
-struct GreedyTail;
 struct LabHooks {
     bool (*ffn_covers)(const GemvArgs& a);                                        // gate/up: a laboratory form takes this launch
     int (*ffn_launch)(const GemvArgs& a, int waves);
-    bool (*qkv_covers)(const GemvArgs& a);                                        // q/k/v
-    int (*qkv_launch)(const GemvArgs& a);
-    // final norm + classifier with the greedy sampler as the launch's epilogue (knob 12): returns true when it took the launch (rc in *rc)
-    bool (*cls_argmax)(q4_half* logits, const q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, int* rc);
 };
 extern LabHooks g_lab;      // gemv_ffn_strip.hip
-#ifdef Q4_PROFILING
-extern int g_cls_argmax;    // exp/lab.hip: profiling knob 12, the greedy sampler as the classifier launch's epilogue
-#endif
-// the greedy sampler launch that would follow the classifier (argmax_kernel's arguments), for the classifier launch to take over; words: the
-// model's CLS hand-off words (one arrival counter, one pad, CLS_SYNC_BLOCKS candidates of 8 bytes), zero between launches
-enum { CLS_SYNC_BLOCKS = 1024, CLS_SYNC_WORDS = 2 + 2 * CLS_SYNC_BLOCKS };
-struct GreedyTail { unsigned* words; int* result; volatile int* pPos; int* pPosGpu; int write_token; q4_half* x_next; const q4_half* table; };
-static inline size_t cls_sync_offset(int dim) { return (attention_sync_words(dim) + 1) & ~(size_t)1; }   // 8-byte aligned, behind the attention words
-static inline size_t ffn_pair_sync_offset(int dim) { return cls_sync_offset(dim) + CLS_SYNC_WORDS; }     // (even: granules are 8 bytes)
-int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded);   // q4_kernels.hip
+static inline size_t ffn_pair_sync_offset(int dim) { return (attention_sync_words(dim) + 1) & ~(size_t)1; }   // 8-byte aligned (granules), behind the attention words
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab);   // q4_kernels.hip
 // Opt `kernel` in to `bytes` of dynamic LDS (more than 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize), once per (kernel, device):
 // a process-wide flag would leave a second device's kernels at 64 KiB after q4_set_device. Not a stream operation: outside any capture.
 int lds_opt_in(const void* kernel, size_t bytes);

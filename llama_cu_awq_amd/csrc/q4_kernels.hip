@@ -289,8 +289,6 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 9) g_ao_mute = slots;       // the attention blocks of the next `slots` attention -> o-proj launches do not publish
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
     if (kind == 15) g_ao_hold_pct = slots;  // split-context bins: the o-proj role's weight requests held back this share of the K / V stream's estimated duration
-    if (kind == 14) g_att_ring = slots;     // 0: the split-context attention role takes its K / V rows in registers, 1: on LDS-DMA rings (same bits)
-    if (kind == 12) g_cls_argmax = slots;   // 0: the greedy sampler stays a launch of its own behind the classifier
     if (kind == 11) g_gemv_form = slots;    // a GemvForm (q4_internal.h): 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings
     if (kind == 16) g_fp_pre = slots;       // FFN pair launch (gemv_ffn_pair.h): down pieces requested in front of a wave's first gather pass
     if (kind == 17) g_fp_mute = slots;
@@ -497,8 +495,6 @@ int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pP
 // final rmsnorm + classifier (llama2_q4.cu:336, 339) as ONE launch where the strips form covers the shape: the norm is computed once per CU inside it and x
 // itself is left un-normalised (nothing reads it afterwards: the next step's embedding overwrites it); elsewhere the two launches of the reference
 namespace q4 {
-// tail != nullptr: the caller's next launch would be the greedy sampler with these arguments; *folded says whether this launch took it over
-// (only the strips form does: gemv_strip_cls.h)
 // the LDS opt-in is not a stream operation: q4_set_device and build_transformer make it (q4_runtime.hip), outside any capture
 int cls_strip_prepare() {
     int rc = Q4_OK;     // (once per device: lds_opt_in)
@@ -508,14 +504,9 @@ int cls_strip_prepare() {
     if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<10, false, CLS_D>, StripClsLds<10, CLS_D>::BYTES);
     return rc;
 }
-// (the greedy sampler as this launch's epilogue -- bit-identical, measured level, not shipped -- is exp/cls_argmax.h: it answers through g_lab)
-int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab, const GreedyTail* tail, bool* folded) {
-    if (folded) *folded = false;
-    if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) {
-        int rc = Q4_OK;
-        if (tail && folded && g_lab.cls_argmax && g_lab.cls_argmax(logits, x, rms_w, wcls, dim, vocab, tail, &rc)) { *folded = true; return rc; }
-        return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab);
-    }
+// (the greedy sampler as this launch's epilogue was built and measured level in round 4: EXPERIMENTS.md #19)
+int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab) {
+    if (cls_strip_covers(dim, vocab, 1, dim, 1.0f)) return launch_cls_strip(logits, x, rms_w, wcls, dim, vocab);
     const int rc = q4_rmsnorm(x, x, rms_w, dim);
     return rc ? rc : q4_matmul_f16(logits, x, wcls, dim, vocab, 1, 0, 0, 0, -1, 1.0f);
 }

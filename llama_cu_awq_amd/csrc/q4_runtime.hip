@@ -585,8 +585,7 @@ static inline void arm_timing(int bit) {
 }
 #define Q4_UNLESS(bit, call) do { if (!(g_skip & (bit))) { if (g_time_mask) arm_timing(bit); int rc__ = (call); g_ev_start = g_ev_stop = nullptr; if (rc__) return rc__; } } while (0)
 
-static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding, GreedyTail* tail = nullptr,
-                       bool* folded = nullptr);
+static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding);
 #ifdef Q4_PROFILING
 // tools/error_growth.py: the residual stream after the attention half and after the FFN half of every layer, [n_layers][2][dim] halves on
 // the device (eager launches only: a copy node would be baked into captured graphs)
@@ -600,10 +599,8 @@ int q4_run_llama_network(const int* pPos, const Config* p, RunState* s, const Tr
     return run_network(pPos, p, s, w, seq_len_bin, false);
 }
 // have_embedding: the preceding launch of the stream (the greedy sampler of the previous step, inside one graph replay) has left
-// the token's embedding row in s->x already. tail: the greedy sampler launch the caller would queue next; *folded = the classifier
-// launch has taken it over (gemv_strip_cls.h) and the caller leaves it out
-static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding, GreedyTail* tail, bool* folded) {
-    if (folded) *folded = false;
+// the token's embedding row in s->x already
+static int run_network(const int* pPos, const Config* p, RunState* s, const TransformerWeights* w, int seq_len_bin, bool have_embedding) {
     q4_half* x = s->x;
     const int dim = p->dim;
     const int hidden_dim = p->hidden_dim;
@@ -670,8 +667,7 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
         Q4_LAYER_DUMP(1);
     }
     if (g_fusion >= 1) {      // one launch where the classifier runs as strips (gemv_strip_cls.h): the final norm inside its x staging
-        if (tail) tail->words = sync ? sync + cls_sync_offset(dim) : nullptr;
-        Q4_UNLESS(32, classifier_with_final_norm(s->logits, x, w->rms_final_weight, w->wcls, p->dim, p->vocab_size, (g_skip & 32) ? nullptr : tail, folded));
+        Q4_UNLESS(32, classifier_with_final_norm(s->logits, x, w->rms_final_weight, w->wcls, p->dim, p->vocab_size));
     } else {
         Q4_UNLESS(32, q4_rmsnorm(x, x, w->rms_final_weight, dim));                                         // :336
         Q4_UNLESS(32, q4_matmul_f16(s->logits, x, w->wcls, p->dim, p->vocab_size, 1, 0, 0, 0, -1, 1.0f));  // :339
@@ -874,14 +870,8 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
             // the reference's 1:1 launch list)
             const bool feed = gen_token && nsteps > 1 && g_fusion >= 1;
             for (int i = 0; i < nsteps && !rc; i++) {
-                // greedy steps without the fp32 copy (which reads the position the sampler advances): the sampler is the classifier
-                // launch's epilogue where that launch runs as strips
-                GreedyTail tail = {nullptr, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token,
-                                   feed && i + 1 < nsteps ? s->x : nullptr, w->token_embedding_table};
-                bool folded = false;
-                rc = run_network(s->pos, p, s, w, seq_len_bin, feed && i > 0, greedy && !copyLogits ? &tail : nullptr, &folded);
+                rc = run_network(s->pos, p, s, w, seq_len_bin, feed && i > 0);
                 if (!rc && copyLogits) rc = q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos);
-                if (folded) continue;
                 if (!rc && greedy) {
                     if (feed && i + 1 < nsteps)
                         rc = launch_argmax_feed(s->logits, p->vocab_size, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos,
@@ -909,11 +899,9 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
         Q4_HIP(hipGraphLaunch(gs.exec[graphIndex][variant], g_stream));          // :372 (:384: the sampler launch is in the graph)
         return Q4_OK;
     }
-    GreedyTail tail = {nullptr, &(s->shared_data->tokens[0]), &(s->shared_data->pos), s->pos, gen_token, nullptr, w->token_embedding_table};
-    bool folded = false;
-    Q4_TRY(run_network(s->pos, p, s, w, g_use_graphs == 2 ? seq_len_bin : seq_len, false, greedy && !copyLogits ? &tail : nullptr, &folded));   // :374
+    Q4_TRY(run_network(s->pos, p, s, w, g_use_graphs == 2 ? seq_len_bin : seq_len, false));   // :374
     if (copyLogits) Q4_TRY(q4_copy_logits_at_pos(s->logits_array, s->logits, p->vocab_size, s->pos));   // :377-382
-    return sample_impl(pSampler, s, gen_token, !folded);
+    return sample_impl(pSampler, s, gen_token, true);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -13,10 +13,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("N", [11008, 14336, 1024 * 4 + 8, 4096])
 def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
-    """The fused gate/up GEMV at K = 4096 has three forms (knob 11): -1 = gemv_q4_kernel<MODE_FFN> (the wave-owned kernel), 8 .. 14 = "strips"
-    (csrc/gemv_strip.h: sixteen self-loading waves per CU on LDS-DMA rings; ring depth 2 / 4 / 8, plain and paced issue), 1 .. 6 = the
-    loader / consumer engine (csrc/exp/ffn_engine.h: one loader wave, eight consumer waves, an 8 x 16 KiB ring; vmcnt lag, + 4 with the
-    consumers' next-slot prefetch); 0 = the product's choice (strips from 36 columns per CU on, i.e. for 11008 and 14336 here). Same arithmetic in
+    """The fused gate/up GEMV at K = 4096 has two forms (knob 11): -1 = gemv_q4_kernel<MODE_FFN> (the wave-owned kernel), 8 .. 14 = "strips"
+    (csrc/gemv_strip.h: sixteen self-loading waves per CU on LDS-DMA rings; ring depth 2 / 4 / 8, plain and paced issue: csrc/exp/ffn_strip_variants.h);
+    0 = the product's choice (strips from 36 columns per CU on, i.e. for 11008 and 14336 here). Same arithmetic in
     the same order: bit equality for the 7B and the Mistral hidden sizes, a ragged split over the CUs and the smallest covered width,
     repeated launches (a race between a fill and a read would show as a run-to-run difference)."""
     L = q4.lib()
@@ -26,7 +25,7 @@ def test_gate_up_engine_equals_the_wave_owned_kernel(q4, rng, N):
     dg, du, dx = q4.DevQWeight(*g), q4.DevQWeight(*u), q4.DevBuf(x)
     outs = {}
     try:
-        for engine in (-1, 0, 1, 2, 3, 5, 8, 9, 10, 12, 13, 14):
+        for engine in (-1, 0, 8, 9, 10, 12, 13, 14):
             L.q4_set_gemv_early(11, engine)
             for rep in range(6):
                 dout = q4.DevBuf(nbytes=N * 2)
@@ -337,126 +336,6 @@ def test_one_block_and_v_slice_forms_of_the_attention_role(q4, model, steps):
             af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
             err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())
             assert err <= (5e-3 if pos <= 128 else 1.2e-2), (pos, other, err)   # (histories differ by an ulp from early on; measured 5.4e-3 at 256)
-
-
-@pytest.mark.parametrize("name", ["cls4096", "cls5120", "cls4096_ragged"])
-@pytest.mark.parametrize("graphs", [1, 0])
-def test_greedy_sampler_inside_the_classifier_launch(q4, tmp_path, name, graphs):
-    """Knob 12 (measured neutral, not shipped: EXPERIMENTS.md notebook §9.19): where the classifier runs as strips (dim 4096 / 5120, a
-    production-size vocabulary) the greedy sampler (argmax_kernel, gpu_kernels.h:448-493) becomes that launch's epilogue: per-block
-    candidates, the last block to arrive decides. Every step's token must
-    be the argmax of the logits the same launch stored, ties to the lowest index, in the eight-steps-per-replay graphs (the winner's
-    embedding row fed to the next step), the single-step graphs and the eager sequence; positions advance by one per step."""
-    path = str(tmp_path / (name + ".bin"))
-    synth.write_model(path, name, seed=11)
-    L = q4.lib()
-    L.q4_set_use_graphs(graphs)
-    L.q4_set_gemv_early(12, 1)
-    try:
-        t = q4.Transformer(path)
-        prompt = [1, 400, 22, 7, 513]
-        steps = 60
-        gtoks, tps, timed, secs = t.generate_ids(prompt, steps)
-        t.reset(prompt)
-        ring = list(prompt)
-        for pos in range(steps):
-            t.run_transformer(pos >= len(prompt) - 1)
-            q4.synchronize()
-            assert int(t.pos()) == pos + 1
-            if pos + 1 >= len(prompt):
-                lg = t.logits().astype(np.float32)
-                assert int(t.token(pos + 1)) == int(np.argmax(lg)), pos
-                ring.append(int(t.token(pos + 1)))
-        n = min(len(gtoks), len(ring))
-        assert n >= steps - 1
-        stop = next((i for i in range(1, n) if ring[i] == 2), n)
-        assert list(gtoks[:stop]) == ring[:stop]
-        assert len(set(ring[len(prompt):])) > 3          # a degenerate ring would prove nothing
-        t.close()
-        L.q4_set_gemv_early(12, 0)                           # the same generation with argmax_kernel as a launch of its own
-        t = q4.Transformer(path)
-        assert list(t.generate_ids(prompt, steps)[0]) == list(gtoks)
-        t.close()
-    finally:
-        L.q4_set_gemv_early(12, 0)
-        L.q4_set_use_graphs(1)
-
-
-@pytest.mark.parametrize("model,steps", [("head128_k5120", 140), ("cls5120", 40)])
-@pytest.mark.parametrize("fusion", [3, 1])
-def test_qkv_strips_equal_the_wave_owned_kernel(q4, tmp_path, model, steps, fusion):
-    """The fused q/k/v launch of the 13B shape (K = N = 5120, head 128: rmsnorm + three GEMVs + RoPE + KV write) runs as strips
-    (csrc/exp/qkv_strip.h: ten RoPE pairs per CU, dword-granular LDS-DMA gathers of scales and zeros, the (cos, sin) entries
-    requested between the ring's first pieces; measured slower than the wave-owned kernel and therefore not the product's choice). Knob
-    11 = -1 forces gemv_q4_kernel<MODE_QKV, 3, 4, true, 0, 1, true> everywhere, 0 is the product (the same kernel for this launch), 8 strips
-    wherever covered. Same arithmetic in the same order: logits AND every K / V row written must agree bit for bit, with
-    the epoch word advanced for the attention -> o-proj launch behind it (fusion level 3) and without (level 1)."""
-    L = q4.lib()
-    path = _model_file(model) if model == "head128_k5120" else str(tmp_path / (model + ".bin"))
-    if model != "head128_k5120":
-        synth.write_model(path, model, seed=11)
-    outs = {}
-    try:
-        for engine in (-1, 0, 8):
-            L.q4_set_gemv_early(11, engine)
-            L.q4_set_fusion(fusion)
-            t = q4.Transformer(path)
-            t.reset([1, 5, 9])
-            got = []
-            for pos in range(steps):
-                t.run_transformer(pos >= 2)
-                if pos in (0, 1, 2, 17, 64, 127, 128, steps - 1):
-                    q4.synchronize()
-                    k, v = t.kv_row(0, pos)
-                    got.append((pos, t.logits().view(np.uint16).copy(), k.view(np.uint16).copy(), v.view(np.uint16).copy()))
-            q4.check(L.q4_handoff_status(t.state))
-            outs[engine] = (got, [int(t.token(i)) for i in range(steps + 1)])
-            t.close()
-    finally:
-        L.q4_set_gemv_early(11, 0)
-        L.q4_set_fusion(q4.DEFAULT_FUSION)
-    assert np.isfinite(outs[-1][0][-1][1].view(np.float16).astype(np.float32)).all()
-    for engine in (0, 8):
-        assert outs[engine][1] == outs[-1][1], engine
-        for (pos, lg, k, v), (_, lg0, k0, v0) in zip(outs[engine][0], outs[-1][0]):
-            assert np.array_equal(k, k0) and np.array_equal(v, v0), (engine, pos, "KV rows")
-            assert np.array_equal(lg, lg0), (engine, pos, "logits")
-
-
-@pytest.mark.parametrize("model,steps", [("head128", 1090), ("head128_gqa", 690), ("head64_long", 1290), ("head256", 590), ("tinyllama", 1090),
-                                         ("long16k_h128", 4200)])
-def test_kv_rings_of_the_split_context_attention_role_are_bit_neutral(q4, model, steps):
-    """Split-context bins of the attention -> o-proj launch (round 5): knob 14 = 1 brings a chunk block's K / V rows in on
-    per-wave LDS-DMA rings (csrc/attention.h, RING), 0 (the product) in registers. Same lanes, same bytes, same order of every sum: logits and token
-    rings must be equal BIT FOR BIT at every checkpoint, through bins 512 (64-position chunks), 1024 (128), 2048 and up (256), heads of
-    64 / 128 / 256, multi-head and grouped-query."""
-    L = q4.lib()
-    path = _model_file(model)
-    cps = sorted({511, 512, 513, 600, 1023, 1024, 1030, 2047, 2048, 2100, 4096, 4100, steps - 1} & set(range(steps)))
-    outs = {}
-    timeouts = L.q4_handoff_timeouts()
-    try:
-        for run, knob in enumerate((0, 1, 0)):       # (the third run is the control: the register form against itself)
-            L.q4_set_gemv_early(14, knob)
-            t = q4.Transformer(path)
-            t.reset([1, 5, 9])
-            got = []
-            for pos in range(steps):
-                t.run_transformer(pos >= 2)
-                if pos in cps:
-                    q4.synchronize()
-                    got.append(t.logits().view(np.uint16).copy())
-            q4.check(L.q4_handoff_status(t.state))
-            assert L.q4_handoff_timeouts() == timeouts
-            outs[run] = (got, [int(t.token(i)) for i in range(steps + 1)])
-            t.close()
-    finally:
-        L.q4_set_gemv_early(14, 0)
-    for a, b, pos in zip(outs[0][0], outs[2][0], cps):
-        assert np.array_equal(a, b), "control: the register form differs from itself at position %d" % pos
-    assert outs[0][1] == outs[1][1], "token rings differ"
-    for a, b, pos in zip(outs[0][0], outs[1][0], cps):
-        assert np.array_equal(a, b), "ring form differs from the register form at position %d" % pos
 
 
 @pytest.mark.parametrize("model,steps", [("head128", 1090), ("tinyllama", 1090)])

@@ -12,7 +12,7 @@ from llama_cu_awq_amd import api, synth   # noqa: E402
 
 api.use_profiling_build()
 model = sys.argv[1] if len(sys.argv) > 1 else "7b"
-rings = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
+rings = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0").split(",")]   # (knob 14, the K / V rings of round 5, left the tree in round 6: the value is ignored)
 holds = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0,100,140,180").split(",")]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 path = "/tmp/llama2_q4_synth_%s_seed20240229.bin" % model
