@@ -261,19 +261,28 @@ __device__ void radix_pass_lds(const unsigned (&kv)[SMP_E], int n, int S, int E,
     __syncthreads();
 }
 
-// fp16 inclusive prefix sum in the fixed order of the header + first index with prefix >= threshold, left in *hit
-// (LDS, initialised to INT_MAX by the caller before a barrier). key(i): fp16 bits of the i-th probability.
+// fp16 inclusive prefix sum in the fixed order of the header + first index with prefix >= threshold (returned to every thread; INT_MAX: none).
+// key(i): fp16 bits of the i-th probability.
 // limit < n (candidate subset, see the kernel): only the first `limit` entries of the sorted order are known. A prefix value
 // depends on the entries in front of it alone -- thread totals and wave totals of LATER threads never enter an earlier prefix --,
 // so with the partition of the full vocabulary (E from n) every prefix below `limit` has the bits of the full scan; entries from
 // `limit` on are not searched, and no hit means "not among the candidates".
-template <typename KeyAt>
-__device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot, int* hit, int limit = 0x7fffffff) {
+// INREG: the thread's E <= 32 entries arrive in registers (pk; the caller fetched them with all loads in flight at once), key is not called
+// (the two walks are chains of dependent fp16 additions: with a load in every link thread 0 alone spent 2.7 us of LDS latency on its 2 x 32 entries).
+// Returns the first index whose prefix reaches the threshold (the minimum over the block: a wave minimum, then sixteen words in LDS -- `wmin` --; an LDS
+// atomicMin on a generic pointer inside this shape sent hipcc / ROCm 7.2 into "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base"), or INT_MAX.
+template <bool INREG, typename KeyAt>
+__device__ __forceinline__ int scan_search_phase(KeyAt key, const float (&pk)[SMP_E], int n, float threshold, float* wtot, int* wmin, int limit = 0x7fffffff) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int E = (n + SMP_T - 1) / SMP_T;
     const int lo = tid * E, hi = min(min(n, limit), lo + E);
     float total = 0.f;
-    for (int i = lo; i < hi; i++) total = round_h(total + h2f(key(i, i - lo)));
+    if (INREG) {
+#pragma unroll
+        for (int j = 0; j < SMP_E; j++) if (lo + j < hi) total = round_h(total + pk[j]);
+    } else {
+        for (int i = lo; i < hi; i++) total = round_h(total + h2f(key(i, i - lo)));
+    }
     float v = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -287,11 +296,29 @@ __device__ void scan_search_phase(KeyAt key, int n, float threshold, float* wtot
     const float prev = __shfl_up(v, 1);
     const float excl = lane > 0 ? round_h(base + prev) : base;
     float r = 0.f;
-    for (int i = lo; i < hi; i++) {
-        r = round_h(r + h2f(key(i, i - lo)));
-        if (round_h(excl + r) >= threshold) { atomicMin(hit, i); break; }
+    int found = 0x7fffffff;
+    if (INREG) {
+#pragma unroll
+        for (int j = 0; j < SMP_E; j++)
+            if (lo + j < hi) {
+                r = round_h(r + pk[j]);
+                if (found == 0x7fffffff && round_h(excl + r) >= threshold) found = lo + j;
+            }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            r = round_h(r + h2f(key(i, i - lo)));
+            if (round_h(excl + r) >= threshold) { found = i; break; }
+        }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(found, off); found = o < found ? o : found; }
+    if (lane == 0) wmin[wave] = found;
     __syncthreads();
+    int h = wmin[0];
+#pragma unroll
+    for (int w = 1; w < SMP_W; w++) h = wmin[w] < h ? wmin[w] : h;
+    __syncthreads();                                          // (wtot / wmin may be written again by the caller's next phase)
+    return h;
 }
 
 // Vocabularies of up to 32 x 1024 entries, a multiple of 8: the softmax's elementwise work (a division, an exponential) and its
@@ -353,7 +380,7 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
     extern __shared__ __attribute__((aligned(16))) unsigned dyn[];   // [32768] sort buffer (on-chip path) + [4096] counters
     __shared__ float red[16];
     __shared__ unsigned wtot[16];
-    __shared__ int hit;
+    __shared__ int wmin[16];
     __shared__ int s_token;
     __shared__ float red6[96];
     if (coins != nullptr) coin = coins[*pPosGpu];            // (requested first: a PCIe read that returns under the softmax)
@@ -362,14 +389,18 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
     unsigned* buf = dyn;
     unsigned* cnt = onchip ? dyn + SMP_T * SMP_E : dyn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) hit = 0x7fffffff;
+    int hit = 0x7fffffff;                                     // (block-uniform: the value scan_search_phase returns)
     SMP_STAMP(0);
     unsigned top = 0;
+    u32x4 pq[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // PRE: this thread's probabilities (entries 8 u .. 8 u + 7, u = tid + 1024 k), kept for the candidate path
     if (PRE) {
         // normalise (gpu_kernels.h:549): p = half(half(e) / sum), sum = the 16-lane tree over the wave totals. Elementwise and
         // order-free, so 8 consecutive entries per thread and 16-byte loads / stores
         const float sum = row16_sum(wave_total[lane & 15]);
-        for (int u = tid; u < (n >> 3); u += SMP_T) {
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) {
+            const int u = tid + kq * SMP_T;
+            if (u >= (n >> 3)) break;
             const u32x4 q = reinterpret_cast<const u32x4*>(k0)[u];
             u32x4 o;
 #pragma unroll
@@ -382,6 +413,7 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
                 top = key1 > top ? key1 : top;
             }
             reinterpret_cast<u32x4*>(logits)[u] = o;
+            pq[kq] = o;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(top, off); top = o > top ? o : top; }
@@ -414,12 +446,127 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
                 const int i0 = tid * SMP_E + c * 8;
                 kq[c] = i0 < n ? *reinterpret_cast<const u32x4*>(keys + i0) : (u32x4){0u, 0u, 0u, 0u};
             }
-            scan_search_phase([&](int, int j) { return (uint16_t)(kq[j >> 3][(j >> 1) & 3] >> ((j & 1) * 16)); }, n, threshold, red, &hit);
+            float pk[SMP_E];
+#pragma unroll
+            for (int j = 0; j < SMP_E; j++) pk[j] = h2f((uint16_t)(kq[j >> 3][(j >> 1) & 3] >> ((j & 1) * 16)));
+            hit = scan_search_phase<true>([](int, int) { return (uint16_t)0; }, pk, n, threshold, red, wmin);
         } else {
-            scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
+            { float pk[SMP_E] = {}; hit = scan_search_phase<false>([&](int i, int) { return keys[i]; }, pk, n, threshold, red, wmin); }
         }
         if (tid == 0) token = hit == 0x7fffffff ? n - 1 : hit;                   // indices[t] == t
     } else if (onchip) {                                                         // sampler.h:60-69
+        bool done = false;
+        // ---- the nucleus first. The search stops at the first sorted entry whose prefix reaches the threshold, and a prefix is a function of the entries
+        // in front of it: only the LARGEST probabilities matter. The entries >= 2^-12 (at most 4096 of them: they sum to <= 1; 260-739 at -t 0.5 on the
+        // synthetic 7B model's logits, tools/lab/logit_stats.py) are appended, straight from the registers the normalising pass left them in and in ANY order,
+        // to four lists by binary exponent -- [2^-9, 1), [2^-10, 2^-9), [2^-11, 2^-10), [2^-12, 2^-11) -- through four LDS counters. The smallest prefix of
+        // lists whose mass (fp32, for choosing only) covers the threshold with a margin is the candidate set; a candidate's place in the descending stable
+        // order is the size of the lists in front of its own plus the number of members of its OWN list that precede it (key, then the lower index: the
+        // packed word key << 16 | 0xFFFF - index), counted in one loop over that list. Then the fp16 scan with the partition of the full vocabulary.
+        // No radix pass, no ordered compaction, no second read of the probabilities; a hit among the candidates is the full sort's hit, bit for bit (the
+        // cut is a key value: equal keys are complete classes). No hit, a list above 1024 entries or a flat distribution fall through to the paths below.
+        if (PRE) {
+            unsigned* lists = const_cast<unsigned*>(cnt);                        // [4][1024] candidates by exponent band: the radix passes' counter area, which this path
+                                                                                 // does not use (the scatter below may touch every word of `buf`)
+            if (tid < 4) wtot[tid] = 0u;
+            __syncthreads();
+            // (single appends: a wave scan of per-list counts with one atomic per wave and list was measured SLOWER, 10.5 -> 17 us for the phase -- one
+            // instruction per thread of this 1024-thread block is 7 ns of the CU's issue time, and the scan's two passes over the 32 entries cost more of them
+            // than the few hundred LDS atomics they replace)
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++)
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const unsigned w2 = pq[kq][d];
+                    if (((w2 & 0xFFFFu) >= (3u << 10)) | ((w2 >> 16) >= (3u << 10))) {       // (rare: one dword in thirty holds a candidate)
+#pragma unroll
+                        for (int hh = 0; hh < 2; hh++) {
+                            const unsigned pb = (w2 >> (16 * hh)) & 0xffffu;
+                            if (pb >= (3u << 10)) {                                      // fp16 bits of 2^-12: exponent field 3
+                                const unsigned ex = pb >> 10;                            // 3 .. 15
+                                const unsigned band = ex >= 6u ? 0u : 6u - ex;           // 2^-9 and above: 0; 2^-10: 1; 2^-11: 2; 2^-12: 3
+                                const unsigned slot = atomicAdd(&wtot[band], 1u);
+                                if (slot < (unsigned)SMP_T) lists[band * SMP_T + slot] = (pb << 16) | (0xFFFFu - ((unsigned)(tid + kq * SMP_T) * 8u + 2u * d + hh));
+                            }
+                        }
+                    }
+                }
+            __syncthreads();
+            const unsigned n0 = wtot[0], n1 = wtot[1], n2 = wtot[2], n3 = wtot[3];
+            if (n0 <= (unsigned)SMP_T && n1 <= (unsigned)SMP_T && n2 <= (unsigned)SMP_T && n3 <= (unsigned)SMP_T) {      // (block-uniform)
+                // the lists' masses: thread t adds entry t of each
+                float b0 = tid < (int)n0 ? h2f((uint16_t)(lists[tid] >> 16)) : 0.f, b1 = tid < (int)n1 ? h2f((uint16_t)(lists[SMP_T + tid] >> 16)) : 0.f;
+                float b2 = tid < (int)n2 ? h2f((uint16_t)(lists[2 * SMP_T + tid] >> 16)) : 0.f, b3 = tid < (int)n3 ? h2f((uint16_t)(lists[3 * SMP_T + tid] >> 16)) : 0.f;
+                b0 = wave_sum(b0); b1 = wave_sum(b1); b2 = wave_sum(b2); b3 = wave_sum(b3);
+                if (lane == 0) { red6[wave] = b0; red6[16 + wave] = b1; red6[32 + wave] = b2; red6[48 + wave] = b3; }
+                __syncthreads();
+                b0 = row16_sum(red6[lane & 15]); b1 = row16_sum(red6[16 + (lane & 15)]); b2 = row16_sum(red6[32 + (lane & 15)]); b3 = row16_sum(red6[48 + (lane & 15)]);
+                const float need = threshold * 1.01f + 0.004f;
+                int nb = 0;                                                      // lists taken
+                if (b0 >= need) nb = 1; else if (b0 + b1 >= need) nb = 2; else if (b0 + b1 + b2 >= need) nb = 3; else if (b0 + b1 + b2 + b3 >= need) nb = 4;
+                const int s1 = (int)n0, s2 = s1 + (int)n1, s3 = s2 + (int)n2, s4 = s3 + (int)n3;
+                const int m = nb == 1 ? s1 : nb == 2 ? s2 : nb == 3 ? s3 : nb == 4 ? s4 : 0;
+                if (m > 0 && m <= SMP_T) {
+                    if (tid < m) {
+                        const int band = tid < s1 ? 0 : tid < s2 ? 1 : tid < s3 ? 2 : 3;
+                        const int first = band == 0 ? 0 : band == 1 ? s1 : band == 2 ? s2 : s3, cnt_b = band == 0 ? (int)n0 : band == 1 ? (int)n1 : band == 2 ? (int)n2 : (int)n3;
+                        const unsigned* lb = lists + band * SMP_T;
+                        const unsigned mine = lb[tid - first];
+                        unsigned before = 0;
+                        for (int i = 0; i < cnt_b; i++) before += lb[i] > mine ? 1u : 0u;      // (neighbouring lanes read one word: mostly an LDS broadcast)
+                        const unsigned rank = (unsigned)first + before, t = rank / (unsigned)E;
+                        buf[(rank - t * (unsigned)E) * SMP_T + t] = (mine & 0xFFFF0000u) | (0xFFFFu - (mine & 0xFFFFu));     // transposed for the FULL partition, as radix_pass_lds<.., true>
+                    }
+                    __syncthreads();
+                    // the scan: m <= 1024 = the entries of threads 0 .. 31 when E = 32 (in general of the first ceil(m / E) threads) -- if those sit in
+                    // wave 0, that wave alone runs scan_search_phase's arithmetic (its base is 0, no other wave's total enters): no block barrier
+                    if ((m + E - 1) / E <= 64) {
+                        if (wave == 0) {
+                            const int lo = tid * E, hi = min(m, lo + E);
+                            float pk[SMP_E];
+#pragma unroll
+                            for (int j = 0; j < SMP_E; j++) pk[j] = h2f((uint16_t)(buf[j * SMP_T + tid] >> 16));     // (stride 1024: conflict-free)
+                            float total = 0.f;
+#pragma unroll
+                            for (int j = 0; j < SMP_E; j++) if (lo + j < hi) total = round_h(total + pk[j]);
+                            float v = total;
+#pragma unroll
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const float o = __shfl_up(v, off);
+                                if (lane >= off) v = round_h(v + o);
+                            }
+                            const float prev = __shfl_up(v, 1);
+                            const float excl = lane > 0 ? round_h(0.f + prev) : 0.f;
+                            float r = 0.f;
+                            int found = 0x7fffffff;
+#pragma unroll
+                            for (int j = 0; j < SMP_E; j++)
+                                if (lo + j < hi) {
+                                    r = round_h(r + pk[j]);
+                                    if (found == 0x7fffffff && round_h(excl + r) >= threshold) found = lo + j;
+                                }
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(found, off); found = o < found ? o : found; }
+                            if (lane == 0) wmin[0] = found;
+                        }
+                        __syncthreads();
+                        hit = wmin[0];
+                    } else {
+                        float pk[SMP_E];
+#pragma unroll
+                        for (int j = 0; j < SMP_E; j++) pk[j] = h2f((uint16_t)(buf[j * SMP_T + tid] >> 16));
+                        hit = scan_search_phase<true>([](int, int) { return (uint16_t)0; }, pk, n, threshold, red, wmin, m);
+                    }
+                    done = hit != 0x7fffffff;
+                    if (done && tid == 0) {
+                        const int mi = hit, t = mi / E;
+                        token = (int)(buf[(mi - t * E) * SMP_T + t] & 0xffffu);
+                    }
+                }
+            }
+            __syncthreads();                                                     // `buf`, `wtot`, `red6`, `wmin` are written again below
+        }
+        if (!done) {
         const int S = E * 64, seg0 = wave * S;
         unsigned kv[SMP_E];
 #pragma unroll
@@ -435,7 +582,6 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
         // of 32) and scan them with the partition of the full vocabulary. A hit among them is the full sort's hit, bit for bit (equal
         // keys are complete classes: the cut is a key value); no hit -- a flat distribution, the margin too thin -- falls through to
         // the full sort below. Trained models at the CLI's temperatures end here; 92 -> ~30 us per token at vocabulary 32000.
-        bool done = false;
         {
             constexpr unsigned C0 = (15u - 9u) << 26, C1 = (15u - 11u) << 26, C2 = (15u - 12u) << 26;   // fp16 2^-9, 2^-11, 2^-12 << 16
             float m0 = 0.f, m1 = 0.f, m2 = 0.f;
@@ -489,9 +635,11 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
                 for (int j = 0; j < SMP_E; j++) kc[j] = (j * 64 < S2 && sg + j * 64 + lane < m) ? buf[sg + j * 64 + lane] : 0u;
                 __syncthreads();
                 radix_pass_lds<23, 8, true>(kc, m, S2, E, buf, cnt, wtot);       // transposed for the FULL partition (E entries per thread)
-                if (tid == 0) hit = 0x7fffffff;
                 __syncthreads();
-                scan_search_phase([&](int, int j) { return (uint16_t)(buf[j * SMP_T + tid] >> 16); }, n, threshold, red, &hit, m);
+                { float pk[SMP_E];
+#pragma unroll
+                  for (int j = 0; j < SMP_E; j++) pk[j] = h2f((uint16_t)(buf[j * SMP_T + tid] >> 16));     // (a thread's E consecutive entries: stride 1024, conflict-free)
+                  hit = scan_search_phase<true>([](int, int) { return (uint16_t)0; }, pk, n, threshold, red, wmin, m); }
                 done = hit != 0x7fffffff;                                        // (block-uniform: read after the phase's last barrier)
                 if (done && tid == 0) {
                     const int mi = hit, t = mi / E;
@@ -501,7 +649,6 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
             }
         }
         if (!done) {
-        if (tid == 0) hit = 0x7fffffff;
         radix_pass_lds<16, 7, false>(kv, n, S, E, buf, cnt, wtot);   // key bits 0-6
 #pragma unroll
         for (int j = 0; j < SMP_E; j++) {
@@ -510,18 +657,22 @@ __global__ void __launch_bounds__(SMP_T) topp_sample_kernel(q4_half* logits, int
         }
         __syncthreads();                                                         // all segments are in registers
         radix_pass_lds<23, 8, true>(kv, n, S, E, buf, cnt, wtot);     // key bits 7-14 (bit 15 is the sign: 0)
-        scan_search_phase([&](int, int j) { return (uint16_t)(buf[j * SMP_T + tid] >> 16); }, n, threshold, red, &hit);
+        { float pk[SMP_E];
+#pragma unroll
+                  for (int j = 0; j < SMP_E; j++) pk[j] = h2f((uint16_t)(buf[j * SMP_T + tid] >> 16));     // (a thread's E consecutive entries: stride 1024, conflict-free)
+                  hit = scan_search_phase<true>([](int, int) { return (uint16_t)0; }, pk, n, threshold, red, wmin); }
         if (tid == 0) {
             const int mi = hit == 0x7fffffff ? n - 1 : hit;                      // gpu_kernels.h:560,574
             const int t = mi / E;
             token = (int)(buf[(mi - t * E) * SMP_T + t] & 0xffffu);
         }
         }
+        }
     } else {
         radix_pass(logits, nullptr, k0, v0, n, 0, cnt, wtot);
         radix_pass(k0, v0, k1, v1, n, 8, cnt, wtot);
         const uint16_t* keys = k1;
-        scan_search_phase([&](int i, int) { return keys[i]; }, n, threshold, red, &hit);
+        { float pk[SMP_E] = {}; hit = scan_search_phase<false>([&](int i, int) { return keys[i]; }, pk, n, threshold, red, wmin); }
         if (tid == 0) token = v1[hit == 0x7fffffff ? n - 1 : hit];
     }
     SMP_STAMP(6);
