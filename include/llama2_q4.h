@@ -234,13 +234,16 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * 64-byte V slice, the stand-alone kernel 4; 8 waves instead of 16): logits agree within the model's tolerance in every bin, not
  * bit for bit. After a timed-out hand-off the library runs level 1 for the next 16 sequences (32, 64, ... after further
  * time-outs), then tries the level it had again; q4_set_fusion(level) re-arms it at once. Resets captured graphs.
- * 4 (default): additionally the FFN half of a layer (rmsnorm + gate/up + SiLU + down projection + residual add, llama2_q4.cu:326-332) as ONE
+ * 4: additionally the FFN half of a layer (rmsnorm + gate/up + SiLU + down projection + residual add, llama2_q4.cu:326-332) as ONE
  * launch where q4_ffn_pair_covers says so (Llama-2-7B's dim / hidden_dim): one block per CU computes its slice of hb, hands it to every
  * other CU inside the launch and multiplies its columns of the down projection, whose weights it has meanwhile streamed into LDS;
- * 3 launches/layer, bit-identical to levels 1 / 3 (same bounded waits, same fallback after a time-out). */
+ * 3 launches/layer, bit-identical to levels 1 / 3 (same bounded waits, same fallback after a time-out).
+ * 5 (default): that launch also runs rmsnorm + q/k/v + RoPE + KV write of the NEXT layer (llama2_q4.cu:300-317) as its third phase, on
+ * weights it streams into LDS while it multiplies the down projection -- multi-head models of Llama-2-7B's shape; 2 launches/layer (the
+ * first layer keeps its own QKV launch, the last layer's FFN half runs as at level 4), bit-identical as well. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
-/* 1: at fusion level 4 a layer's FFN half of these sizes runs as one launch on the current device and stream (csrc/gemv_ffn_pair.h) */
+/* 1: at fusion levels 4 / 5 a layer's FFN half of these sizes runs as one launch on the current device and stream (csrc/gemv_ffn_pair.h) */
 int q4_ffn_pair_covers(int dim, int hidden_dim);
 /* 1 (default): hipGraph capture/replay as USE_CUDA_GRAPHS llama2_q4.cu:33; 0: eager launches with the exact context length (the
  * reference's other path, :374); 2: eager launches with the graph path's sequence-length bin -- exactly what the graphs run, one launch

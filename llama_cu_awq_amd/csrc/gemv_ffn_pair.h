@@ -11,7 +11,13 @@
 //            K-split kernel's permuted layout over the dead gate/up rings.
 //   phase 2  the down projection's dot products on weights that are already in LDS: units (column, k-part), lanes, slots and the part-0-then-part-1
 //            sum of gemv_q4_kernel<MODE_PLAIN, 3, 4, false, 0, 2> (= down_strip_kernel<3, false>), residual add, one rounding.
-// Same arithmetic in the same order as the two launches it replaces: bit for bit (tests/prof_cases.py, tests/test_forward_gpu.py).
+//   phase 3  (fusion level 5, template QKV) rmsnorm + q/k/v + RoPE + KV write of the NEXT layer (gemv_q4_kernel<MODE_QKV, 2, 4, true>, gpu_kernels.h:72-105,
+//            242-254, 332-355; llama2_q4.cu:300-317): the block's 48 q / k / v columns (eight RoPE pairs of each matrix) stream into the LDS the down weights
+//            have left, one request in front of each of phase 2's dot-product steps; the block's 16 new values of x leave as granules, waves 0 .. 7 gather the
+//            vector and run the QKV kernel's x chain (512 chunk partials, canonical reduction, norm folded into the staging) while every wave unpacks its
+//            pieces; dot products on resident weights, the RoPE epilogue from the rotation table, q and the K / V rows of the position; one thread
+//            advances the epoch for the attention -> o-proj launch behind it.
+// Same arithmetic in the same order as the launches it replaces: bit for bit (tests/test_ffn_pair_gpu.py, tests/prof_cases.py).
 // Protocol (as layer_attn.h): the tag is the model's epoch word, advanced by the PRECEDING fused QKV launch; every block is producer first and
 // consumer second, producers wait for nobody, so the launch cannot wedge while all blocks are resident (grid = CUs of the device, the stream unmasked:
 // ffn_pair_covers); every wait is bounded and a run-out sets the model's sticky error word (q4_handoff_status: one clean retry at fusion level 1).
@@ -34,6 +40,21 @@ struct FfnPairArgs {
     unsigned long long* dbg;   // profiling build: [block][64] wall-clock stamps
 };
 
+// phase 3 (fusion level 5): rmsnorm + q/k/v + RoPE + KV write of the NEXT layer (the launch then replaces gemv_q4_kernel<MODE_QKV, 2, 4, true> as well)
+struct QkvNextArgs {
+    GemvMat m[3];              // q, k, v of the next layer (K = N = dim = 4096, multi-head: kv_dim == dim)
+    const q4_half* rms_w;      // its rms_att_weight
+    q4_half* q;                // RunState::q
+    q4_half* kc;               // key / value cache of the next layer (its layer offset applied by the host)
+    q4_half* vc;
+    const int* pPos;
+    const float2* rope_table;  // [seq_len][head_size / 2] (cos, sin)
+    u32x2v* xgran;             // dim / 2 granules {x[2 g], x[2 g + 1], tag}: the residual stream between phases 2 and 3
+    unsigned* bump;            // the epoch word of the attention -> o-proj launch that follows (advanced once, at the very end, by block 0)
+    int head_size, kv_dim;
+    unsigned ppb;              // RoPE pairs (i, i + head_size / 2) per block and matrix: dim / 2 / blocks (8)
+};
+
 constexpr int FP_ROWS = 6;             // 64-unit rows of the staged hb vector: hidden <= 12288
 constexpr int FP_NC2MAX = 16;          // down projection columns per block
 struct FfnPairLds {
@@ -45,17 +66,23 @@ struct FfnPairLds {
     static constexpr unsigned DSIDE_S = TOT2 + 256u;                // 3 KiB: 16 columns x <= 96 groups x 2 B
     static constexpr unsigned DSIDE_Z = DSIDE_S + 3072u;            // 1 KiB: 16 columns x <= 16 words x 4 B
     static constexpr unsigned DW = DSIDE_Z + 1024u;                 // the block's columns of the down projection, as they lie in the tensor
-    static constexpr unsigned DW_BYTES = 88u * 1024u;
-    static constexpr unsigned BYTES = DW + DW_BYTES;
+    static constexpr unsigned DW_BYTES = 96u * 1024u;               // (phase 3 keeps the block's 48 q / k / v columns of 2 KiB here once the down weights are unpacked)
+    static constexpr unsigned QSIDE_S = DW + DW_BYTES;              // 3 KiB: 48 columns x 32 groups x 2 B
+    static constexpr unsigned QSIDE_Z = QSIDE_S + 3072u;            // 1 KiB: 48 columns x 4 words x 4 B
+    static constexpr unsigned STAMP2 = QSIDE_Z + 1024u;             // profiling build: [64] more stamps ([0..15] phase 2 done per wave, [16..31] phase 3 done per wave, [32..] the second seam)
+    static constexpr unsigned BYTES = STAMP2 + 512u;
+    // phase 3's x chain re-uses phase 1's (dead since barrier A, clear of the staged hb vector): G::XS, G::SX, G::PART; its column totals: G::TOT
 };
 static_assert(FfnPairLds::BYTES <= 160 * 1024, "one block per CU");
+static_assert(FfnPairLds::QSIDE_S % 16 == 0, "alignment");
 static_assert(FfnPairLds::DW % 16 == 0 && FfnPairLds::TOT2 % 16 == 0, "alignment");
 constexpr unsigned FP_POLL_LIMIT = 1u << 18;    // gather passes without a down piece in between (each a memory round trip + s_sleep): ~0.3 s, then give up
 
 #define FPSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
-template <bool NORM, bool STAMPS>
+#define FPSTAMP2(k) do { if (STAMPS && lane == 0) reinterpret_cast<unsigned long long*>(smem + P::STAMP2)[(k)] = wall_clock64(); } while (0)
+template <bool NORM, bool STAMPS, bool QKV = false>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
-                                                                    const unsigned pbase, const unsigned prem, const GemvArgs a, const FfnPairArgs p) {
+                                                                    const unsigned pbase, const unsigned prem, const GemvArgs a, const FfnPairArgs p, const QkvNextArgs q3) {
     constexpr int TS = 2, D = 2;
     constexpr unsigned CB = 2048u, G = 32u, ZW = 4u;
     constexpr int NSTAGE = 8;
@@ -78,7 +105,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     const unsigned voff = lane * 16u;
     const bool stager = wave < NSTAGE;
     unsigned long long* st = reinterpret_cast<unsigned long long*>(smem + L::STAMP);
-    if (STAMPS && wave == 0) { st[lane] = 0ull; FPSTAMP(0); }     // [0] entry, [1..3] x chain, [4] barrier A, [5] published, [6..7] wave 1 first pass / complete, [9] barrier B, [10] dots, [11] stored,
+    if (STAMPS && wave == 0) { st[lane] = 0ull; reinterpret_cast<unsigned long long*>(smem + P::STAMP2)[lane] = 0ull; FPSTAMP(0); }     // [0] entry, [1..3] x chain, [4] barrier A, [5] published, [6..7] wave 1 first pass / complete, [9] barrier B, [10] dots, [11] stored,
                                                                   // [12] passes; per wave: [16 + w] gathered, [32 + w] gate/up done, [48 + w] down pieces landed
 
     // ---- entry, as ffn_strip_kernel: x first, then the hand-off word, the side data of both phases, then the ring
@@ -246,7 +273,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     const unsigned nch2 = (unsigned)p.Kd >> 3;
     const unsigned tail = ku - 128u;
     // phase 2's weights, unpacked while the wave waits for the vector: [unit][slot][dword] x {n0 n4, n1 n5 << 4, n2 n6, n3 n7 << 4} as fp16 denormal pairs
+    // (the last piece of each phase stays packed -- four registers instead of sixteen: the kernel lives at the 128 registers a lane has at sixteen waves per CU)
     unsigned pm[2][3][16];
+    u32x4 wlast = {0u, 0u, 0u, 0u};
     auto unpack = [&](const int ifirst, const int ilast) {
 #pragma unroll
         for (int i = ifirst; i <= ilast; i++) {
@@ -257,6 +286,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                 const unsigned uj = unit < uend ? unit : uend - 1u;
                 u32x4 w = {0u, 0u, 0u, 0u};
                 if (i < nu2) w = *reinterpret_cast<const u32x4*>(smem + P::DW + (lc * (unsigned)p.pw4 + uj) * 16u);
+                if (i == 1 && ks == 2) { wlast = w; asm volatile("" : "+v"(wlast)); continue; }
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const unsigned ww = w[d], tt = ww >> 8;
@@ -359,7 +389,29 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     }
     block_barrier_lds();                               // barrier B: hb staged (every wave's own down pieces have landed and are unpacked)
     if (wave == 1) FPSTAMP(9);
-
+    // ---- phase 3's geometry: the block owns the RoPE pairs pair0 .. pair0 + 7 of q, k and v: 48 columns cw (matrix cw / 16, RoPE half (cw % 16) / 8, pair cw % 8),
+    // wave w multiplies cw = 3 w + j
+    const unsigned hp3 = QKV ? (unsigned)q3.head_size >> 1 : 1u;
+    const unsigned pair0 = QKV ? blockIdx.x * q3.ppb : 0u;             // the block's first RoPE pair (of every matrix); its pairs stay inside one head
+    const unsigned n0q = QKV ? (pair0 / hp3) * (unsigned)q3.head_size + pair0 % hp3 : 0u;   // first column of the block's lower run; the upper run: + head_size / 2
+    // Its stream goes out PIECE BY PIECE during phase 2, one request in front of each of the wave's six dot-product steps (the down weights sit in registers
+    // since barrier B: their LDS is free). All at once -- at barrier B, or behind the dot products -- the 100 requests of a CU stall in ISSUE (a CU takes
+    // 32-40 KiB in flight) and hold their waves: phase 2 then takes 3.6 us instead of 1.9, or barrier C is reached 2.2 us late (tools/lab/ffn_pair_check.py).
+    auto issue_qkv = [&](const int r) {                 // request r = 0 .. 5 of this wave: column cw = 3 wave + r / 2, k-slot r % 2; with r = 0 also a piece of side data
+        const unsigned cw = 3u * (unsigned)wave + (unsigned)(r >> 1), m = cw >> 4, n = n0q + (((cw >> 3) & 1u) ? hp3 : 0u) + (cw & 7u);
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)q3.m[m].w, 0, (int)(a.K * 2048), 0x00020000);   // dim columns of 2 KiB
+        dma_piece(P::DW + cw * 2048u + (unsigned)(r & 1) * 1024u, voff, rq, n * 2048u + (unsigned)(r & 1) * 1024u);
+        if (r == 0 && wave < 12) {                     // the six runs of eight columns: 512 B of scales (waves 0 .. 5), 128 B of zero words (6 .. 11)
+            const unsigned run = wave < 6 ? (unsigned)wave : (unsigned)wave - 6u, ms = run >> 1, ns = n0q + ((run & 1u) ? hp3 : 0u);
+            if (wave < 6) {
+                const __amdgpu_buffer_rsrc_t rs = rsrc_from(q3.m[ms].s, ns * 64u, (unsigned)a.K * 64u);
+                if (lane < 32u) dma_piece_default(P::QSIDE_S + run * 512u, voff, rs, 0u);
+            } else {
+                const __amdgpu_buffer_rsrc_t rz = rsrc_from(q3.m[ms].z, ns * 16u, (unsigned)a.K * 16u);
+                if (lane < 8u) dma_piece_default(P::QSIDE_Z + run * 128u, voff, rz, 0u);
+            }
+        }
+    };
     // ---- phase 2: down_strip_kernel<3, false>'s units; a k-slot's inputs are read once for both units of the wave
     const uint16_t resid = (uint16_t)resid_raw;
     {
@@ -384,6 +436,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             const unsigned zsh = ((uj >> 2) & 7u) * 4u;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
+                if (QKV) issue_qkv(2 * ks + i);                 // (three requests under the dot products and three behind them: 1009 -> 1000 tokens/s)
                 if (i < nu2) {
                     const unsigned lc = ((unsigned)wave >> 1) + 8u * (unsigned)i;
                     const uint16_t sc = *reinterpret_cast<const uint16_t*>(smem + P::DSIDE_S + (lc * (unsigned)p.sh + (uj >> 2)) * 2u);
@@ -392,7 +445,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
                         unsigned m0, m1, m2, m3;
-                        m0 = pm[i][ks][4 * d + 0]; m1 = pm[i][ks][4 * d + 1]; m2 = pm[i][ks][4 * d + 2]; m3 = pm[i][ks][4 * d + 3];
+                        if (i == 1 && ks == 2) { const unsigned ww = wlast[d], tt = ww >> 8; m0 = ww & 0x000F000Fu; m1 = ww & 0x00F000F0u; m2 = tt & 0x000F000Fu; m3 = tt & 0x00F000F0u; }
+                        else { m0 = pm[i][ks][4 * d + 0]; m1 = pm[i][ks][4 * d + 1]; m2 = pm[i][ks][4 * d + 2]; m3 = pm[i][ks][4 * d + 3]; }
                         acc_e = __builtin_amdgcn_fdot2(as_h2(m0), as_h2(X[d][0]), acc_e, false);
                         acc_o = __builtin_amdgcn_fdot2(as_h2(m1), as_h2(X[d][1]), acc_o, false);
                         acc_e = __builtin_amdgcn_fdot2(as_h2(m2), as_h2(X[d][2]), acc_e, false);
@@ -414,23 +468,173 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const int row = lane >> 4;
         if ((lane & 15u) == 0 && row < nu2) tot2[wave + 16 * row] = total;      // [column][k-part] = unit index
         if (wave == 1) FPSTAMP(10);
-        if (STAMPS && lane == 0) reinterpret_cast<unsigned long long*>(smem + P::DW + 87u * 1024u)[wave] = wall_clock64();   // (the 88th KiB: free at Llama-2-7B)
+        FPSTAMP2(wave);
         block_barrier_lds();
+        if (wave == 0) FPSTAMP2(32);
+        uint16_t xnew = 0;
         if ((int)tid < nc2) {
             float r = tot2[2 * tid];
             r += tot2[2 * tid + 1];                     // fixed order: k-parts from the lowest up
             r += h2f(resid);                            // gpu_kernels.h:229-230
-            p.xio[c0d + tid] = f2h(r);                  // :231
+            xnew = f2h(r);
+            p.xio[c0d + tid] = xnew;                    // :231
         }
+        if (QKV && wave == 0) {                         // the block's slice of the new residual stream, for every other block: column pairs (c0d and nc2 are even)
+            const unsigned partner = (unsigned)__shfl_down((int)xnew, 1);
+            if ((lane & 1u) == 0u && (int)lane < nc2) store_granule(q3.xgran + ((c0d + lane) >> 1), (unsigned)xnew | (partner << 16), tag);
+        }
+    }
+    if (QKV) {
+        if (wave == 0) { FPSTAMP(13); FPSTAMP2(33); }
+        // ---- the second seam: x from every block (dim / 8 chunks of eight halves: one per thread of waves 0 .. 7), the next layer's norm weights, the
+        // position and its (cos, sin) entries; meanwhile every wave unpacks its q / k / v pieces
+        const unsigned nch3 = (unsigned)a.K >> 3;                        // 512
+        const bool gath = tid < nch3;
+        u32x4 xr3 = {0u, 0u, 0u, 0u}, wr3 = {0u, 0u, 0u, 0u};
+        unsigned pm3[3][2][16];
+        u32x4 wlast3 = {0u, 0u, 0u, 0u};
+        auto unpack3 = [&](const int jfirst, const int jlast) {
+#pragma unroll
+            for (int j = jfirst; j <= jlast; j++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(smem + P::DW + ((3u * (unsigned)wave + (unsigned)j) * 128u + 64u * (unsigned)ks + lane) * 16u);
+                    if (j == 2 && ks == 1) { wlast3 = w; asm volatile("" : "+v"(wlast3)); continue; }
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d], tt = ww >> 8;
+                        pm3[j][ks][4 * d + 0] = ww & 0x000F000Fu;
+                        pm3[j][ks][4 * d + 1] = ww & 0x00F000F0u;
+                        pm3[j][ks][4 * d + 2] = tt & 0x000F000Fu;
+                        pm3[j][ks][4 * d + 3] = tt & 0x00F000F0u;
+                    }
+                    asm volatile("" : "+v"(pm3[j][ks][0]), "+v"(pm3[j][ks][1]), "+v"(pm3[j][ks][2]), "+v"(pm3[j][ks][3]), "+v"(pm3[j][ks][4]), "+v"(pm3[j][ks][5]), "+v"(pm3[j][ks][6]), "+v"(pm3[j][ks][7]),
+                                 "+v"(pm3[j][ks][8]), "+v"(pm3[j][ks][9]), "+v"(pm3[j][ks][10]), "+v"(pm3[j][ks][11]), "+v"(pm3[j][ks][12]), "+v"(pm3[j][ks][13]), "+v"(pm3[j][ks][14]), "+v"(pm3[j][ks][15]));
+                }
+        };
+        wait_vmcnt<0>();                                 // this wave's q / k / v pieces have landed (wave 0: its stores are acknowledged)
+        if (gath) {
+            const u32x4* pw = reinterpret_cast<const u32x4*>(q3.rms_w) + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wr3) : "v"(pw) : "memory");
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)q3.xgran, 0, (int)(nch3 * 32u), 0x00020000);
+            bool need = true;
+            unsigned tries = 0, passes = 0;
+            bool failed = false;
+            for (;;) {
+                u32x4 g0, g1;
+                const unsigned o0 = need ? tid * 32u : 0x7FFFFF00u;
+                // sc1 from the first pass on: the blocks reach this seam up to a microsecond apart, an early plain read would leave stale lines in the L1
+                asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1" : "=&v"(g0), "=&v"(g1) : "v"(o0), "s"(rg) : "memory");
+                if (passes == 0) unpack3(0, 1);         // under the first pass (the third column behind it, when the pass's registers are free again)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(g0), "+v"(g1), "+v"(wr3) : : "memory");
+                if (need && g0[1] == tag && g0[3] == tag && g1[1] == tag && g1[3] == tag) { xr3 = (u32x4){g0[0], g0[2], g1[0], g1[2]}; need = false; }
+                if (STAMPS && passes == 0 && wave == 1) FPSTAMP2(34);
+                passes++;
+                if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+                if (++tries >= FP_POLL_LIMIT || dead != 0u) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed && dead == 0u && lane == 0) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STAMPS && wave == 1) { FPSTAMP2(35); if (lane == 0) reinterpret_cast<unsigned long long*>(smem + P::STAMP2)[39] = passes; }
+            unpack3(2, 2);
+        } else {
+            unpack3(0, 2);
+        }
+        if (wave == 1) FPSTAMP(14);
+        // the x chain of gemv_q4_kernel<MODE_QKV, 2, 4, true>: 512 chunk partials, the canonical reduction, the norm folded into the staging
+        u32x4* xs3 = reinterpret_cast<u32x4*>(smem + L::XS);
+        float* sx3 = reinterpret_cast<float*>(smem + L::SX);
+        float* part3 = reinterpret_cast<float*>(smem + L::PART);
+        float* tot3 = reinterpret_cast<float*>(smem + L::TOT);
+        if (gath) part3[tid] = sumsq8(xr3, 0.f);
+        block_barrier_lds();
+        if (wave == 1) FPSTAMP2(36);
+        if (gath) {
+            const float ss = rms_scale_from_partials<512>(part3, 512, a.K);
+            const unsigned sgn = q4_stage_sign_bits(tid);
+            const u32x4 v = rms_apply8(xr3, wr3, q4_signed_scale(ss, sgn));
+            const u32x4 pv = permute_x8(v);
+            const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+            float cb = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+            cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+            const unsigned j = tid >> 2, d = tid & 3u;
+            xs3[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+            if (d == 0) sx3[j] = cb * -9.5367431640625e-07f;
+        }
+        // position and rotation of the block's pairs (threads 0 .. 47: one column each), requested now, used behind the dot products
+        int pos3 = 0;
+        float2 cs3 = {1.f, 0.f};
+        if (tid < 48u) {
+            pos3 = *q3.pPos;
+            cs3 = q3.rope_table[(size_t)pos3 * hp3 + (pair0 % hp3) + (tid & 7u)];
+        }
+        block_barrier_lds();                             // x staged
+        if (wave == 1) { FPSTAMP(15); FPSTAMP2(37); }
+        {
+            float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                u32x4 X[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) X[d] = xs3[((ks * 4 + d) << 6) + lane];
+                const float corr = sx3[ks * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const unsigned cw = 3u * (unsigned)wave + (unsigned)j;
+                    const uint16_t sc = *reinterpret_cast<const uint16_t*>(smem + P::QSIDE_S + (cw * 32u + 16u * (unsigned)ks + (lane >> 2)) * 2u);
+                    const unsigned zw = *reinterpret_cast<const unsigned*>(smem + P::QSIDE_Z + (cw * 4u + 2u * (unsigned)ks + (lane >> 5)) * 4u);
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        unsigned m0, m1, m2, m3;
+                        if (j == 2 && ks == 1) { const unsigned ww = wlast3[d], tt = ww >> 8; m0 = ww & 0x000F000Fu; m1 = ww & 0x00F000F0u; m2 = tt & 0x000F000Fu; m3 = tt & 0x00F000F0u; }
+                        else { m0 = pm3[j][ks][4 * d + 0]; m1 = pm3[j][ks][4 * d + 1]; m2 = pm3[j][ks][4 * d + 2]; m3 = pm3[j][ks][4 * d + 3]; }
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(m0), as_h2(X[d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(m1), as_h2(X[d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(m2), as_h2(X[d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(m3), as_h2(X[d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((zw >> (((lane >> 2) & 7u) * 4u)) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr, t);
+                    cs[j] = __builtin_fmaf(h2f(sc), t, cs[j]);
+                }
+            }
+            const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
+            const int row = lane >> 4;
+            if ((lane & 15u) == 0 && row < 3) tot3[3 * wave + row] = total;
+        }
+        FPSTAMP2(16 + wave);
+        block_barrier_lds();
+        if (tid < 48u) {                                 // the epilogue of gemv_q4_kernel<MODE_QKV>: RoPERotation_kernel (gpu_kernels.h:332-355) on the fp16-rounded outputs, KV write (:251, 253)
+            const unsigned m = tid >> 4, upper = (tid >> 3) & 1u, c = tid & 7u;
+            const float mine = tot3[tid];
+            float r = mine;
+            if (m < 2u) {
+                const float other = round_h(tot3[tid ^ 8u]), me = round_h(mine);
+                const float fcr = cs3.x, fci = cs3.y;
+                r = upper ? (other * fci + me * fcr) : (me * fcr - other * fci);    // :345-346
+            }
+            const unsigned n = n0q + (upper ? hp3 : 0u) + c;
+            q4_half* out = m == 0u ? q3.q : (m == 1u ? q3.kc : q3.vc) + (size_t)pos3 * (size_t)q3.kv_dim;
+            out[n] = f2h(r);
+        }
+        if (wave == 0) FPSTAMP2(38);
+        // the epoch of the attention -> o-proj launch behind this one (gemv_q4.h, `bump`): advanced by one thread of the launch, at its very end
+        if (q3.bump != nullptr && blockIdx.x == 0 && tid == 0) __hip_atomic_fetch_add(q3.bump, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (STAMPS) {
         if (wave == 0) FPSTAMP(11);
         block_barrier_lds();
         if (p.dbg && tid < 64u) p.dbg[(size_t)blockIdx.x * 64 + tid] = st[tid];
-        if (p.dbg && tid < 16u) p.dbg[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 16 + tid] = reinterpret_cast<unsigned long long*>(smem + P::DW + 87u * 1024u)[tid];   // dots done, per wave
+        if (p.dbg && tid < 64u) p.dbg[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 64 + tid] = reinterpret_cast<unsigned long long*>(smem + P::STAMP2)[tid];
     }
 }
 #undef FPSTAMP
+#undef FPSTAMP2
 
 // Shapes: gate/up K = dim = 4096 (two 1 KiB pieces per column), whole column pairs per CU, 8 .. 28 of them; down projection K = hidden in two k-parts of
 // three slots with an ordinary last one (Llama-2-7B: 172 = 64 + 64 + 44 units), at most 16 output columns per CU whose weights fit the 88 KiB the launch keeps

@@ -13,8 +13,19 @@ static void fill_gate_up(GemvArgs& a, int dim, int hidden) {
     a.K = dim; a.N = hidden; a.pw4 = g.pw4; a.pzh = g.pzh; a.sh = g.sh; a.nslots = g.nslots;
 }
 
-// words the launch needs behind the model's other hand-off words: hidden / 2 granules of 8 bytes
-size_t ffn_pair_sync_words(int hidden) { return (size_t)(hidden / 2) * 2; }
+// words the launch needs behind the model's other hand-off words: hidden / 2 granules of 8 bytes for hb, then dim / 2 for the residual stream
+// between its second and third phase (fusion level 5)
+size_t ffn_pair_sync_words(int dim, int hidden) { return (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 2; }
+
+// fusion level 5: the launch also runs rmsnorm + q/k/v + RoPE + KV write of the NEXT layer. Multi-head models with 128-wide heads and a rotation table
+// (every Llama-2-7B-shaped model): a block's eight RoPE pairs stay inside one head.
+bool ffn_qkv_covers(int dim, int hidden, int kv_dim, int head_size, bool have_rope_table) {
+    if (!ffn_pair_covers(dim, hidden) || kv_dim != dim || !have_rope_table || head_size < 16 || (head_size & 1)) return false;
+    const int nb = cu_count(), hp = head_size / 2;
+    if ((dim / 2) % nb) return false;
+    const int ppb = dim / 2 / nb;
+    return ppb == 8 && hp % ppb == 0 && dim / nb == 16 && 48 * 2048 <= (int)FfnPairLds::DW_BYTES;
+}
 
 bool ffn_pair_covers(int dim, int hidden) {
     if ((dim & 7) || (hidden & 31)) return false;
@@ -26,15 +37,17 @@ bool ffn_pair_covers(int dim, int hidden) {
 // 146 KiB of LDS: the opt-in is not a stream operation -- build_transformer makes it for the model, outside any capture
 int ffn_pair_prepare() {
     int rc = lds_opt_in((const void*)ffn_pair_kernel<true, false>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true>, FfnPairLds::BYTES);
 #ifdef Q4_PROFILING
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true>, FfnPairLds::BYTES);
 
 #endif
     return rc;
 }
 
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word, unsigned tag_add) {
+                    unsigned* sync, size_t gran_word, unsigned tag_add, const FfnQkvNext* next) {
     if (!rms_w || !sync || !ffn_pair_covers(dim, hidden)) return Q4_ERR_UNSUPPORTED_SIZE;
     { const int rc = ffn_pair_prepare(); if (rc) return rc; }
     GemvArgs a = {};
@@ -54,23 +67,27 @@ int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight
     p.dbase = (unsigned)dim / nb; p.drem = (unsigned)dim % nb;
     p.pre = (unsigned)g_fp_pre;
     p.tag_add = tag_add;
+    QkvNextArgs q3 = {};
+    if (next) {
+        const int kv_dim = next->kv_dim, head_size = next->head_size;
+        if (!ffn_qkv_covers(dim, hidden, kv_dim, head_size, next->rope_table != nullptr)) return Q4_ERR_UNSUPPORTED_SIZE;
+        fill_mat(q3.m[0], next->wq); fill_mat(q3.m[1], next->wk); fill_mat(q3.m[2], next->wv);
+        q3.rms_w = next->rms_w; q3.q = next->q; q3.kc = next->kc; q3.vc = next->vc; q3.pPos = next->pPos; q3.rope_table = next->rope_table;
+        q3.xgran = reinterpret_cast<u32x2v*>(sync + gran_word + (size_t)(hidden / 2) * 2);
+        q3.bump = next->bump; q3.head_size = head_size; q3.kv_dim = kv_dim; q3.ppb = (unsigned)(dim / 2) / nb;
+    }
     const unsigned pairs = (unsigned)hidden / 2u;
+#define FP_GO(...) do { Q4_LAUNCH((ffn_pair_kernel<__VA_ARGS__>), dim3(nb), dim3(STRIP_WAVES * 64), FfnPairLds::BYTES, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w), \
+                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p, q3); Q4_LAUNCH_CHECK(); return Q4_OK; } while (0)
 #ifdef Q4_PROFILING
     if (g_fp_mute > 0) { p.mute = 1; g_fp_mute--; }
     p.dbg = g_dbg;
-#define FP_GO(...) do { Q4_LAUNCH((ffn_pair_kernel<__VA_ARGS__>), dim3(nb), dim3(STRIP_WAVES * 64), FfnPairLds::BYTES, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w), \
-                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p); Q4_LAUNCH_CHECK(); return Q4_OK; } while (0)
-    if (g_dbg) {
-        Q4_LAUNCH((ffn_pair_kernel<true, true>), dim3(nb), dim3(STRIP_WAVES * 64), FfnPairLds::BYTES, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
-                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p);
-        Q4_LAUNCH_CHECK();
-        return Q4_OK;
-    }
+    if (g_dbg && next) FP_GO(true, true, true);
+    if (g_dbg && g_fusion < 5) FP_GO(true, true, false);        // (at level 5 the stamps are the three-phase launches': the last layer's plain pair launch does not overwrite them)
 #endif
-    Q4_LAUNCH((ffn_pair_kernel<true, false>), dim3(nb), dim3(STRIP_WAVES * 64), FfnPairLds::BYTES, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w),
-              (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p);
-    Q4_LAUNCH_CHECK();
-    return Q4_OK;
+    if (next) FP_GO(true, false, true);
+    FP_GO(true, false, false);
+#undef FP_GO
 }
 
 }  // namespace q4

@@ -44,7 +44,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
 static void forget_bench_granules(int kernel_id, const Config* p, RunState* s) {
     unsigned* sync = sync_words_of_state(s);
     if (kernel_id != 10 || !sync) return;
-    (void)hipMemsetAsync(sync + ffn_pair_sync_offset(p->dim), 0, ffn_pair_sync_words(p->hidden_dim) * sizeof(unsigned), g_stream);
+    (void)hipMemsetAsync(sync + ffn_pair_sync_offset(p->dim), 0, ffn_pair_sync_words(p->dim, p->hidden_dim) * sizeof(unsigned), g_stream);
     (void)hipStreamSynchronize(g_stream);
 }
 

@@ -138,10 +138,17 @@ int launch_ffn_fused(q4_half* out, const q4_half* x, const q4_half* rms_w, const
 // rmsnorm + gate/up + SiLU + down projection + residual as ONE launch (gemv_ffn_pair.h; fusion level 4). Its granules lie behind the model's other
 // hand-off words, at word ffn_pair_sync_offset(dim)
 bool ffn_pair_covers(int dim, int hidden);
-size_t ffn_pair_sync_words(int hidden);
+size_t ffn_pair_sync_words(int dim, int hidden);
+// ... and (fusion level 5) the next layer's rmsnorm + q/k/v + RoPE + KV write as the launch's third phase
+struct FfnQkvNext {
+    const q4_half* rms_w; const QWeight* wq; const QWeight* wk; const QWeight* wv;
+    q4_half* q; q4_half* kc; q4_half* vc;        // RunState::q; the next layer's cache rows (layer offset applied)
+    const int* pPos; const float2* rope_table; unsigned* bump; int kv_dim, head_size;
+};
+bool ffn_qkv_covers(int dim, int hidden, int kv_dim, int head_size, bool have_rope_table);
 int ffn_pair_prepare();     // gemv_ffn_pair.hip: LDS opt-in, outside any stream capture
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word, unsigned tag_add = 0);
+                    unsigned* sync, size_t gran_word, unsigned tag_add = 0, const FfnQkvNext* next = nullptr);
 unsigned* sync_words_of_state(const RunState* s);   // q4_runtime.hip: the model's hand-off words, or null
 extern int g_fp_pre, g_fp_mute, g_fp_nt;
 

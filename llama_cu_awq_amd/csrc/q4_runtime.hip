@@ -14,12 +14,12 @@
 namespace q4 {
 
 hipStream_t g_stream = nullptr;
-int g_fusion = 4;
+int g_fusion = 5;
 int g_multi_steps = Q4_MULTI_STEPS;   // greedy steps per graph replay in the token loops (profiling build: q4_set_gemv_early(7, n))
 int g_use_graphs = 1;
 int g_quiet = 0;
 static int g_rearm_after = 0;          // > 0: sequences left at fusion level 1 before the level in force is tried again (after a timed-out hand-off)
-static int g_rearm_level = 4;          // the fusion level that comes back when the probation ends
+static int g_rearm_level = 5;          // the fusion level that comes back when the probation ends
 static int g_rearm_backoff = 16;       // sequences to sit out after the next time-out: doubles every time, so a box that keeps stalling settles at level 1
 static int g_handoff_timeouts = 0;     // timed-out in-launch waits seen by q4_handoff_status since the library was loaded
 char g_last_error[512] = "";
@@ -230,7 +230,7 @@ int q4_memset(void* dst, int value, size_t bytes) {
 // o-proj as one launch on top of that (default). Level 2 (QKV -> attention -> o-proj as one launch) was measured slower than
 // level 1 in round 2 and removed in round 3: the value selects level 1.
 void q4_set_fusion(int level) {
-    g_fusion = level <= 0 ? 0 : level >= 4 ? 4 : level == 3 ? 3 : 1;
+    g_fusion = level <= 0 ? 0 : level >= 5 ? 5 : level == 4 ? 4 : level == 3 ? 3 : 1;
     g_rearm_after = 0;          // an explicit choice ends the probation after a time-out (and is the documented way to re-arm at once)
     q4_reset_graphs();
     if (g_stream)
@@ -493,7 +493,7 @@ int q4_build_transformer(Transformer* t, const char* checkpoint_path, int perple
     g_slabs[t] = slabs;
     if (rc) { q4_free_transformer(t); return rc; }
     if (slabs.rope_table) g_rope_by_state[&t->state] = slabs.rope_table;
-    const size_t sync_words = ffn_pair_sync_offset(p->dim) + ffn_pair_sync_words(p->hidden_dim);
+    const size_t sync_words = ffn_pair_sync_offset(p->dim) + ffn_pair_sync_words(p->dim, p->hidden_dim);
     if (hipMalloc((void**)&slabs.sync, sync_words * sizeof(unsigned)) == hipSuccess) {
         // zeroed on the launch stream and waited for: nothing else orders a null-stream memset before the first launch on a
         // non-blocking g_stream when the caller starts with q4_run_transformer instead of q4_reset_sequence
@@ -621,13 +621,18 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
 
     // :326-332 as ONE launch (gemv_ffn_pair.h) where the shapes and the stream admit it; its tag is the same epoch word
     const bool fp = g_fusion >= 4 && sync && ffn_pair_covers(dim, hidden_dim);
+    // ... and the next layer's :300-317 with it (fusion level 5): that layer then has no QKV launch of its own
+    const bool fq = fp && g_fusion >= 5 && ffn_qkv_covers(dim, hidden_dim, kv_dim, head_size, rope_table != nullptr);
+    bool qkv_done = false;                             // the previous launch has left q and the K / V rows of this layer
 
     for (int l = 0; l < p->n_layers; l++) {
         const PerLayerWeight* L = &w->layers[l];
         // :303. 64-bit: the reference's int overflows at e.g. 13B x 16384 positions (40 * 16384 * 5120 > 2^31); the
         // int-typed entry points of the 1:1 path get pre-offset cache pointers and loff = 0 instead
         const long long loff = (long long)l * p->seq_len * kv_dim;
-        if (g_fusion) {
+        if (qkv_done) {
+            qkv_done = false;
+        } else if (g_fusion) {
             // rmsnorm (:300) + qkv (:307, or the three GEMVs of the GQA branch :310-312) + RoPE (:317) in one launch
             Q4_UNLESS(1, launch_qkv_fused(s->q, s->key_cache, s->value_cache, x, L->rms_att_weight, &L->wq_q, &L->wq_k, &L->wq_v,
                                           dim, kv_dim, loff, pPos, head_size, p->rope_theta, rope_table, (ao || fp) ? sync + SYNC_EPOCH : nullptr));
@@ -653,7 +658,17 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
         }
         Q4_LAYER_DUMP(0);
         if (fp) {
-            Q4_UNLESS(8, launch_ffn_pair(x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden_dim, sync, ffn_pair_sync_offset(dim)));   // :326-332
+            FfnQkvNext nx = {};
+            const bool with_next = fq && l + 1 < p->n_layers && !(g_skip & 9);
+            if (with_next) {
+                const PerLayerWeight* N = &w->layers[l + 1];
+                const long long noff = (long long)(l + 1) * p->seq_len * kv_dim;
+                nx = FfnQkvNext{N->rms_att_weight, &N->wq_q, &N->wq_k, &N->wq_v, s->q, s->key_cache + noff, s->value_cache + noff, pPos, rope_table,
+                                sync + SYNC_EPOCH, kv_dim, head_size};
+            }
+            Q4_UNLESS(8, launch_ffn_pair(x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden_dim, sync, ffn_pair_sync_offset(dim), 0u,
+                                         with_next ? &nx : nullptr));   // :326-332 (+ the next layer's :300-317)
+            qkv_done = with_next;
             Q4_LAYER_DUMP(1);
             continue;
         }

@@ -66,8 +66,8 @@ GEOMETRIES = {
     # the FFN half of a layer as one launch (csrc/gemv_ffn_pair.h, fusion level 4): Llama-2-7B's dim / hidden at two layers; a hidden size that
     # splits raggedly over 256 CUs (20.5 column pairs per CU; a last k-slot of 36 units); and the widest the launch's LDS holds (22 pairs, 48)
     "ffn_pair7b": (4096, 11008, 2, 32, 32, 512, 300, 10000.0),
-    "ffn_pair_ragged": (4096, 10496, 1, 32, 32, 512, 300, 10000.0),
-    "ffn_pair_wide": (4096, 11264, 1, 32, 32, 512, 300, 10000.0),
+    "ffn_pair_ragged": (4096, 10496, 2, 32, 32, 512, 300, 10000.0),
+    "ffn_pair_wide": (4096, 11264, 2, 32, 32, 512, 300, 10000.0),
 }
 
 

@@ -61,7 +61,7 @@ def test_library_loads_without_gpu_and_reports_status_strings():
     L = api.lib()
     assert L.q4_status_string(0) == b"ok"
     assert L.q4_status_string(1) == b"Unsupported matmul size. Exiting"      # llama2_q4.cu:215
-    assert L.q4_get_fusion() == 4                                            # default: fused kernels, attention -> o-proj and the FFN pair as one launch each
+    assert L.q4_get_fusion() == 5                                            # default: attention -> o-proj as one launch, the FFN half + the next layer's QKV as another
 
 
 def test_struct_layouts_match_the_reference():

@@ -135,7 +135,7 @@ def test_contract_tolerance_at_full_depth_on_a_contractive_7b(q4, orc, observed)
     item 2a). The random-weight 7B / 13B models above are chaotic by construction (a rounding that falls the other way is amplified by every layer behind
     it), so their bound is the f64 bracket; `7b_contractive` is the same shape, the same 32 layers and seeds with the scales of the residual-writing
     matrices (o, down) x 0.25: what remains between two fp16 evaluations is what the arithmetic itself contributes. 32 positions in lockstep, every fusion
-    level (4: the FFN half as one launch; 3; 1; 0: the reference's 1:1 launch list), greedy tokens exact outside near-ties."""
+    level (5: the FFN half + the next layer's QKV as one launch; 4: the FFN half as one launch; 3; 1; 0: the reference's 1:1 launch list), greedy tokens exact outside near-ties."""
     path = _model("7b_contractive")
     L = q4.lib()
     m = orc.Model(path)
@@ -143,7 +143,7 @@ def test_contract_tolerance_at_full_depth_on_a_contractive_7b(q4, orc, observed)
     toks = list(PROMPT)
     rec = observed.setdefault("contract_7b_contractive", {})
     try:
-        for level in (3, 4, 1, 0):
+        for level in (3, 5, 4, 1, 0):
             L.q4_set_fusion(level)
             t = q4.Transformer(path)
             t.reset(PROMPT)

@@ -1,6 +1,7 @@
 """The FFN half of a layer as ONE launch (csrc/gemv_ffn_pair.h, fusion level 4; llama2_q4.cu:326-332): rmsnorm + gate/up + SiLU, the hb vector
-handed from every CU to every CU inside the launch, the down projection on weights that are already in LDS, residual add. Same arithmetic in the
-same order as the two launches of levels 1 / 3, so everything the network leaves behind must agree BIT FOR BIT."""
+handed from every CU to every CU inside the launch, the down projection on weights that are already in LDS, residual add -- and, at fusion level 5,
+the NEXT layer's rmsnorm + q/k/v + RoPE + KV write (llama2_q4.cu:300-317) as the launch's third phase. Same arithmetic in the same order as the
+launches of levels 1 / 3, so everything the network leaves behind must agree BIT FOR BIT."""
 import numpy as np
 import pytest
 
@@ -52,6 +53,8 @@ def test_level_4_reproduces_the_launch_sequence_bits(q4, models, name, steps, gr
         a = _run(q4, models[name], 3, graphs, steps, prompt)
         b = _run(q4, models[name], 4, graphs, steps, prompt)
         assert L.q4_get_fusion() == 4 and L.q4_handoff_timeouts() == before
+        c = _run(q4, models[name], 5, graphs, steps, prompt)
+        assert L.q4_get_fusion() == 5 and L.q4_handoff_timeouts() == before
     finally:
         L.q4_set_fusion(q4.DEFAULT_FUSION)
         L.q4_set_use_graphs(1)
@@ -59,13 +62,17 @@ def test_level_4_reproduces_the_launch_sequence_bits(q4, models, name, steps, gr
     assert a[2] == b[2], "greedy token rings differ"
     assert np.array_equal(a[0], b[0]), "logits differ at positions %s" % np.unique(np.argwhere(a[0] != b[0])[:, 0])[:8]
     assert np.array_equal(a[1], b[1]), "K / V rows differ at positions %s" % np.unique(np.argwhere(a[1] != b[1])[:, 0])[:8]
+    # level 5: the two-layer model has ONE launch with the third phase (layer 0's FFN + layer 1's QKV); q, every K / V row and the logits are its witnesses
+    assert a[2] == c[2], "greedy token rings differ (level 5)"
+    assert np.array_equal(a[0], c[0]), "logits differ at positions %s (level 5)" % np.unique(np.argwhere(a[0] != c[0])[:, 0])[:8]
+    assert np.array_equal(a[1], c[1]), "K / V rows differ at positions %s (level 5)" % np.unique(np.argwhere(a[1] != c[1])[:, 0])[:8]
 
 
 def test_level_4_against_the_restatement(q4, orc, models):
     """... and against the CPU restatement of run_llama_network (oracle/), the model's bound of tests/test_forward_gpu.py."""
     L = q4.lib()
     try:
-        L.q4_set_fusion(4)
+        L.q4_set_fusion(5)
         t = q4.Transformer(models["ffn_pair7b"])
         m = orc.Model(models["ffn_pair7b"])
         prompt = [1, 17, 300, 45, 9]
@@ -94,7 +101,7 @@ def test_shapes_the_launch_does_not_cover_run_the_launch_sequence(q4, tmp_path):
     synth.write_model(p, "head128", seed=7)
     try:
         a = _run(q4, p, 3, 1, 20, [1, 5, 9])
-        b = _run(q4, p, 4, 1, 20, [1, 5, 9])
+        b = _run(q4, p, 5, 1, 20, [1, 5, 9])
     finally:
         L.q4_set_fusion(q4.DEFAULT_FUSION)
     assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

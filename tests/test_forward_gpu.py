@@ -36,7 +36,7 @@ def _logit_close(gpu, ref, bound=5e-3):
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_gqa", "small", "longk_gqa", "head128", "head128_k5120", "head128_gqa", "tinyllama", "head256",
                                   "head128_k8192", "head96", "head80_gqa"])
-@pytest.mark.parametrize("fusion,graphs", [(4, 1), (3, 1), (1, 1), (0, 1), (3, 0), (1, 0), (0, 0)])
+@pytest.mark.parametrize("fusion,graphs", [(5, 1), (3, 1), (1, 1), (0, 1), (3, 0), (1, 0), (0, 0)])
 def test_forward_logits_and_kv(q4, orc, models, name, fusion, graphs):
     L = q4.lib()
     L.q4_set_fusion(fusion)

@@ -20,7 +20,8 @@ t = api.Transformer(path)
 L.q4_set_gemv_early(16, pre % 1000); L.q4_set_gemv_early(18, pre // 1000)
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
 out = {}
-for lvl in (3, 4):
+LEVELS = (3, 4, 5)
+for lvl in LEVELS:
     L.q4_set_fusion(lvl)
     for graphs in (0, 1):
         L.q4_set_use_graphs(graphs)
@@ -36,35 +37,36 @@ for lvl in (3, 4):
     out[(lvl, "ring")] = t.generate_ids(prompt, 64)[0].copy()
     print("level %d: fusion now %d, hand-off time-outs %d" % (lvl, L.q4_get_fusion(), L.q4_handoff_timeouts()), flush=True)
 ok = True
-for g in (0, 1):
+for lv in LEVELS[1:]:
+  for g in (0, 1):
     for k, name in ((0, "logits"), (1, "kv rows")):
-        same = np.array_equal(out[(3, g)][k], out[(4, g)][k])
+        same = np.array_equal(out[(3, g)][k], out[(lv, g)][k])
         ok &= same
-        print("graphs %d %-8s level 4 == level 3: %s" % (g, name, same), flush=True)
+        print("graphs %d %-8s level %d == level 3: %s" % (g, name, lv, same), flush=True)
         if not same:
-            d = np.argwhere(out[(3, g)][k] != out[(4, g)][k])
+            d = np.argwhere(out[(3, g)][k] != out[(lv, g)][k])
             print("   first differences (pos, index):", d[:8].tolist(), " count", len(d))
-same = np.array_equal(out[(3, "ring")], out[(4, "ring")])
-ok &= same
-print("token rings equal: %s" % same, flush=True)
+  same = np.array_equal(out[(3, "ring")], out[(lv, "ring")])
+  ok &= same
+  print("token rings equal (level %d): %s" % (lv, same), flush=True)
 print("finite logits:", bool(np.isfinite(out[(4, 1)][0].view(np.float16).astype(np.float32)).all()))
 
 # speed, interleaved
 for pre in pres:
   L.q4_set_gemv_early(16, pre % 1000); L.q4_set_gemv_early(18, pre // 1000)
-  res = {3: [], 4: []}
+  res = {l: [] for l in LEVELS}
   for rep in range(3):
-    for lvl in (3, 4):
+    for lvl in LEVELS:
         L.q4_set_fusion(lvl)
         t.generate_ids(prompt, ntok)
         res[lvl].append(max(t.generate_ids(prompt, ntok)[1] for _ in range(3)))
-  for lvl in (3, 4):
-    print("per token: level 3 %.4f ms, level 4 %.4f ms, difference %.1f us" % (1e3 / np.median(res[3]), 1e3 / np.median(res[4]), 1e6 / np.median(res[3]) - 1e6 / np.median(res[4]))) if lvl == 4 else None
+  for lvl in LEVELS:
+    print("per token: level 3 %.4f ms, level %d %.4f ms, difference %.1f us" % (1e3 / np.median(res[3]), lvl, 1e3 / np.median(res[lvl]), 1e6 / np.median(res[3]) - 1e6 / np.median(res[lvl]))) if lvl != 3 else None
     print("pre %d level %d  -n %d  best-of-3 tokens/s per round: %s   median %.1f" % (pre, lvl, ntok, " ".join("%.1f" % v for v in res[lvl]), float(np.median(res[lvl]))), flush=True)
   print("time-outs:", L.q4_handoff_timeouts(), "fusion:", L.q4_get_fusion())
 
 # timeline of one launch (eager, profiling build): the stamps of the last layer's launch
-L.q4_set_fusion(4)
+L.q4_set_fusion(int(os.environ.get("TIMELINE_LEVEL", "5")))
 L.q4_set_use_graphs(0)
 nb = 256
 dbg = api.DevBuf(nbytes=4 << 20)
@@ -80,7 +82,11 @@ for trial, pre in enumerate(pres):
     L.q4_set_debug_buffer(None)
     raw = dbg.get(np.uint64)
     st = raw[: nb * 64].reshape(nb, 64).astype(np.int64)
-    dd = raw[nb * 64: nb * 80].reshape(nb, 16).astype(np.int64)
+    s2 = raw[nb * 64: nb * 128].reshape(nb, 64).astype(np.int64)
+    good = (st[:, 11] > 0) & (st[:, 3] > 0)
+    print("blocks with a complete record: %d of %d" % (good.sum(), nb))
+    st, s2 = st[good], s2[good]
+    dd = s2[:, 0:16]
     t0 = st[:, 0].min()
     us = lambda v: (v - t0) * 0.01
 
@@ -95,7 +101,14 @@ for trial, pre in enumerate(pres):
     row("wave 1: first gather pass issued", st[:, 8]); row("wave 1: first gather pass back", st[:, 6]); row("wave 1: gathered", st[:, 7])
     row("gathered, per wave (1..15)", st[:, 17:32]); row("gathered, block's last wave", st[:, 17:32].max(axis=1))
     row("down pieces landed, per wave", st[:, 48:64]); row("down pieces landed, block's last wave", st[:, 48:64].max(axis=1))
-    row("barrier B passed (wave 1)", st[:, 9]); row("wave 1: dots done", st[:, 10]); row("dots done, per wave", dd); row("dots done, block's last wave", dd.max(axis=1)); row("stored (wave 0)", st[:, 11])
+    row("barrier B passed (wave 1)", st[:, 9]); row("wave 1: dots done", st[:, 10])
+    row("phase 2 dots done, per wave", dd); row("phase 2 dots done, block's last wave", dd.max(axis=1))
+    if (s2[:, 33] > 0).all():      # the three-phase launch (fusion level 5)
+        row("barrier C passed (wave 0)", s2[:, 32]); row("x published (wave 0)", s2[:, 33]); row("wave 1: first x pass back", s2[:, 34]); row("wave 1: x gathered", s2[:, 35])
+        row("sum of squares exchanged (wave 1)", s2[:, 36]); row("x staged (wave 1)", s2[:, 37])
+        row("phase 3 dots done, per wave", s2[:, 16:32]); row("phase 3 dots done, block's last wave", s2[:, 16:32].max(axis=1)); row("q / k / v stored (wave 0)", s2[:, 38])
+        print("x gather passes of wave 1: min %d median %d max %d" % (s2[:, 39].min(), np.median(s2[:, 39]), s2[:, 39].max()))
+    row("stored (wave 0)", st[:, 11])
     print("gather passes of wave 1: min %d median %d max %d" % (st[:, 12].min(), np.median(st[:, 12]), st[:, 12].max()))
     last_pub = us(st[:, 5]).max()
     print("last publish %.2f us; launch ends %.2f us; last publish -> end %.2f us" % (last_pub, us(st[:, 11]).max(), us(st[:, 11]).max() - last_pub))
