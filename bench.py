@@ -54,6 +54,8 @@ def kernel_bytes(cfg):
         # fusion level 4: rmsnorm + gate/up + SiLU + down + residual as ONE launch (csrc/gemv_ffn_pair.h): the three QWeights, x and the norm weights in,
         # the residual in, x out, and RunState::hb, which the launch still leaves behind (its in-launch hand-off of hb is not algorithmic traffic)
         10: ("ffn_rmsnorm_gate_up_silu_down_accum_q4", 2 * qweight_bytes(d, h) + qweight_bytes(h, d) + 4 * d * 2 + h * 2),
+        # fusion level 5: ... and rmsnorm + q/k/v + RoPE + KV write of the NEXT layer as the launch's third phase: + three QWeights, the norm weights, q and the two cache rows out
+        11: ("ffn_gate_up_down_accum_then_next_qkv_rope_q4", 2 * qweight_bytes(d, h) + qweight_bytes(h, d) + 4 * d * 2 + h * 2 + 3 * qweight_bytes(d, d) + d * 2 + 3 * d * 2),
     }
 
 
@@ -215,9 +217,10 @@ def main():
     if rank == 0:
         tr.reset(PROMPT_IDS)          # the timed kernels address the KV cache at the device position: back to 0 (after -n 2048 it is seq_len)
         pair = L.q4_get_fusion() >= 4 and L.q4_ffn_pair_covers(cfg.dim, cfg.hidden_dim) == 1    # the FFN half of a layer runs as one launch
-        dom_id = 10 if pair else 0                                                               # the decode path's dominant launch
+        three = pair and L.q4_get_fusion() >= 5 and cfg.n_kv_heads == cfg.n_heads and cfg.dim // cfg.n_heads == 128   # ... with the next layer's QKV inside (csrc/gemv_ffn_pair.hip ffn_qkv_covers)
+        dom_id = 11 if three else 10 if pair else 0                                              # the decode path's dominant launch
         for kid, (name, nbytes) in kb.items():
-            if kid == 10 and not pair:
+            if (kid == 10 and not pair) or (kid == 11 and not three):
                 continue
             tr.bench_kernel(kid, 32)   # warm
             avg, mn, mx = tr.bench_kernel(kid, 256 if kid != 5 else 32)
@@ -245,7 +248,7 @@ def main():
             if os.path.exists(cpath):
                 import csv
                 for r in csv.DictReader(open(cpath)):
-                    if ("ffn_pair_kernel<" in r["kernel"]) if pair else ("gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]):   # the dominant launch: the FFN pair (csrc/gemv_ffn_pair.h), else the fused gate/up launch (csrc/gemv_strip.h)
+                    if (("ffn_pair_kernel<true, false, true>" in r["kernel"]) if three else ("ffn_pair_kernel<" in r["kernel"])) if pair else ("gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]):   # the dominant launch: the FFN pair (csrc/gemv_ffn_pair.h), else the fused gate/up launch (csrc/gemv_strip.h)
                         rocprof_us, rocprof_src = float(r["avg_us"]), "profiles/" + os.path.basename(cpath)
                         break
             if rocprof_us is not None:
@@ -257,7 +260,7 @@ def main():
         kv_dim = cfg.dim * cfg.n_kv_heads // cfg.n_heads
         for cls, nm, kid in ((1, "qkv_rmsnorm_rope_q4", 3), (6, "attention+oproj_accum (one launch, fusion level 3)", None),
                              (16, "gemv_q4_hidden_to_dim_accum", 2), (32, "final_rmsnorm+classifier_f16", 5)):
-            if cls == 16 and pair:      # the down projection is inside the FFN pair launch
+            if (cls == 16 and pair) or (cls == 1 and three):      # the down projection (and, at level 5, every layer's QKV but the first) is inside the FFN launch
                 continue
             p0_ = tr.pos()
             a_, mn_, mx_, n_ = tr.bench_in_network(cls, 4)
@@ -276,14 +279,18 @@ def main():
         in_network[kb[dom_id][0]] = round(net_avg, 3)
         per_kernel[kb[dom_id][0]] = {"hip_event_us": round(net_avg, 3), "graph_us": round(graph_us, 3), "bytes": kb[dom_id][1],
                                      "frac": round(kb[dom_id][1] / kernel_us / 1e3 / HBM_PEAK_GBS, 4), "launches": net_n, "first_position": pos_first}
-        if pair:    # what the launch replaced, on this box: the two launches of fusion level 3, inside the same eager network
+        if pair:    # what the launch replaced, on this box: the launches of fusion level 3, inside the same eager network
+            level_now = L.q4_get_fusion()
             L.q4_set_fusion(3)
             gu_, _, _, ngu_ = tr.bench_in_network(8, 8)
             dn_, _, _, ndn_ = tr.bench_in_network(16, 8)
-            L.q4_set_fusion(4)
-            per_kernel[kb[dom_id][0]]["replaces"] = {"gate_up_launch_us": round(gu_, 3), "down_launch_us": round(dn_, 3), "sum_us": round(gu_ + dn_, 3),
-                                                     "frac_of_the_two": round(kb[dom_id][1] / (gu_ + dn_) / 1e3 / HBM_PEAK_GBS, 4),
-                                                     "note": "fusion level 3's gate/up launch (csrc/gemv_strip.h) and down projection (csrc/gemv_q4.h, K split) by HIP events in the same network"}
+            qk_ = tr.bench_in_network(1, 8)[0] if three else 0.0
+            L.q4_set_fusion(level_now)
+            per_kernel[kb[dom_id][0]]["replaces"] = {"gate_up_launch_us": round(gu_, 3), "down_launch_us": round(dn_, 3), "qkv_launch_us": round(qk_, 3) if three else None,
+                                                     "sum_us": round(gu_ + dn_ + qk_, 3),
+                                                     "frac_of_the_sum": round(kb[dom_id][1] / (gu_ + dn_ + qk_) / 1e3 / HBM_PEAK_GBS, 4),
+                                                     "note": "fusion level 3's gate/up launch (csrc/gemv_strip.h), down projection (csrc/gemv_q4.h, K split) and, where the launch holds it, "
+                                                             "QKV launch by HIP events in the same network"}
         traffic, traffic_src = None, None
         # PMC passes need rocprofv3 around the process: measured separately (tools/profile_round.sh), committed summaries
         for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -294,7 +301,9 @@ def main():
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
                             "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
-                            kb[dom_id][0]: ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
+                            kb[dom_id][0]: ("ffn_pair_kernel<true, false, true>",) if three else ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
+                if three:
+                    prefixes.pop("qkv_rmsnorm_rope_q4", None)
                 for nm_, pre_ in prefixes.items():
                     ratios = [e_["traffic_over_algorithmic"] for k_, e_ in tj_all.get("%s_n%d" % (args.model, ntok), {}).items()
                               if isinstance(e_, dict) and k_.replace("q4::", "").startswith(pre_) and "traffic_over_algorithmic" in e_]   # (str.startswith takes a tuple too)
@@ -341,7 +350,7 @@ def main():
                                                "latency, the x chain, the hand-off and the tail of its stream rather than by VALU issue (DESIGN.md)" if busy_us / dom["us"] < 0.5 else ""),
                                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ...)" % os.path.basename(sq_path)}
         kernels["in_network_us"] = in_network
-        ids4 = (10, 3, 4) if pair else (0, 2, 3, 4)
+        ids4 = (11, 4) if three else (10, 3, 4) if pair else (0, 2, 3, 4)
         int4_bytes = sum(kb[k][1] for k in ids4)
         int4_us = sum(kernels[kb[k][0]]["us"] for k in ids4)
         kernels["int4_gemv_all_per_layer"] = {"us": round(int4_us, 3), "bytes": int4_bytes, "GBps": round(int4_bytes / int4_us / 1e3, 1)}

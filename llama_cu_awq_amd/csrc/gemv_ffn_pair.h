@@ -436,7 +436,8 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             const unsigned zsh = ((uj >> 2) & 7u) * 4u;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                if (QKV) issue_qkv(2 * ks + i);                 // (three requests under the dot products and three behind them: 1009 -> 1000 tokens/s)
+                if (QKV) issue_qkv(2 * ks + i);                 // (three requests under the dot products and three behind them: 1009 -> 1000 tokens/s; 72 KiB of the
+                                                                //  CU's 96 under them, 24 behind: 1012 -> 1005)
                 if (i < nu2) {
                     const unsigned lc = ((unsigned)wave >> 1) + 8u * (unsigned)i;
                     const uint16_t sc = *reinterpret_cast<const uint16_t*>(smem + P::DSIDE_S + (lc * (unsigned)p.sh + (uj >> 2)) * 2u);

@@ -36,6 +36,14 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
             if (!sync) return Q4_ERR_ARG;
             return launch_ffn_pair(s->x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden, sync, ffn_pair_sync_offset(dim), 1u + (unsigned)i);
         }
+        case 11: {   // ... with the next layer's QKV as its third phase (fusion level 5)
+            unsigned* sync = sync_words_of_state(s);
+            if (!sync) return Q4_ERR_ARG;
+            const PerLayerWeight* N = &w->layers[(i + 1) % w->num_layers];
+            const long long noff = (long long)((i + 1) % w->num_layers) * p->seq_len * kv_dim;
+            const FfnQkvNext nx = {N->rms_att_weight, &N->wq_q, &N->wq_k, &N->wq_v, s->q, s->key_cache + noff, s->value_cache + noff, s->pos, rope_table_of(s), nullptr, kv_dim, head_size};
+            return launch_ffn_pair(s->x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden, sync, ffn_pair_sync_offset(dim), 1u + (unsigned)i, &nx);
+        }
     }
     return Q4_ERR_ARG;
 }
@@ -43,7 +51,7 @@ static int launch_by_id(int kernel_id, int i, const Config* p, RunState* s, cons
 // kernel 10 leaves granules tagged beyond the model's epoch behind: cleared, so that no later launch of the network can meet one of them as its own
 static void forget_bench_granules(int kernel_id, const Config* p, RunState* s) {
     unsigned* sync = sync_words_of_state(s);
-    if (kernel_id != 10 || !sync) return;
+    if ((kernel_id != 10 && kernel_id != 11) || !sync) return;
     (void)hipMemsetAsync(sync + ffn_pair_sync_offset(p->dim), 0, ffn_pair_sync_words(p->dim, p->hidden_dim) * sizeof(unsigned), g_stream);
     (void)hipStreamSynchronize(g_stream);
 }
@@ -82,7 +90,7 @@ extern "C" double q4_bench_kernel(int kernel_id, const Config* p, RunState* s, c
                                   double* min_us, double* max_us) {
     if (iters < 1 || !p || !s || !w) return -1.0;
     if (s->shared_data->pos >= p->seq_len) return -1.0;   // the kernels write the KV row of the device position: it must exist
-    if ((kernel_id < 0 || kernel_id > 6) && kernel_id != 10) return -1.0;       // ids 7-9 (tiny launches) are timed inside a graph only
+    if ((kernel_id < 0 || kernel_id > 6) && kernel_id != 10 && kernel_id != 11) return -1.0;       // ids 7-9 (tiny launches) are timed inside a graph only
     std::vector<hipEvent_t> ev(2 * iters);
     for (auto& e : ev)
         if (hipEventCreate(&e) != hipSuccess) return -1.0;

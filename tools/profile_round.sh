@@ -24,7 +24,7 @@ for cfg in "7b 256" "13b 128" "7b 2048"; do
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$1_$2_$c -o k -- python tools/prof_decode.py $1 $2 > $out/pmc_$1_$2_$c.log 2>&1
   done
 done
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $out/pmc_k0_sq -o k -- python tools/prof_kernel.py ${SQ_KERNEL:-10} 32 > $out/pmc_k0_sq.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $out/pmc_k0_sq -o k -- python tools/prof_kernel.py ${SQ_KERNEL:-11} 32 > $out/pmc_k0_sq.log 2>&1
 python tools/summarize_profiles.py $out $tag > $out/summary.log 2>&1
 # the raw traces are hundreds of MB: only the summaries and the logs travel back
 rm -rf $out/trace_*/ $out/pmc_*/
