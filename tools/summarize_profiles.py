@@ -154,7 +154,7 @@ if sq:
         out["cycles_per_valu_instruction"] = round(4.0 * out["SQ_ACTIVE_INST_VALU"] / out["SQ_INSTS_VALU"], 2)
         out["valu_instructions_per_wave"] = round(out["SQ_INSTS_VALU"] / max(1.0, out.get("SQ_WAVES", 1.0)), 1)
     out["note"] = ("rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES over "
-                   "tools/prof_kernel.py <id> 32 (id 10: the FFN pair launch, fusion level 4; id 0: the fused gate/up launch -- over the ring of the layers' weights); SQ_ACTIVE_INST_VALU counts quad-cycles "
+                   "tools/prof_kernel.py <id> 32 (id 11: the FFN half + the next layer's QKV as one launch, fusion level 5; id 10: the FFN pair launch alone, level 4; id 0: the fused gate/up launch -- over the ring of the layers' weights); SQ_ACTIVE_INST_VALU counts quad-cycles "
                    "summed over the chip's 1024 SIMDs (MI355X_MICROARCH.md, per-instruction constants)")
     # (the FFN pair launch, where the round's collection timed kernel 10: the decode path's dominant launch at fusion level 4)
     json.dump(out, open(os.path.join(dst, "%s_sq_counters_%s.json" % (tag, "ffn_pair" if "ffn_pair_kernel" in out.get("kernel", "") else "gate_up")), "w"), indent=1)
