@@ -240,7 +240,10 @@ int q4_run_transformer_steps(int pos, int nsteps, int gen_token, const Config* p
  * 3 launches/layer, bit-identical to levels 1 / 3 (same bounded waits, same fallback after a time-out).
  * 5 (default): that launch also runs rmsnorm + q/k/v + RoPE + KV write of the NEXT layer (llama2_q4.cu:300-317) as its third phase, on
  * weights it streams into LDS while it multiplies the down projection -- multi-head models of Llama-2-7B's shape; 2 launches/layer (the
- * first layer keeps its own QKV launch, the last layer's FFN half runs as at level 4), bit-identical as well. */
+ * first layer keeps its own QKV launch, the last layer's FFN half runs as at level 4), bit-identical as well.
+ * 6 (opt-in; measured 1-2 % SLOWER than 5): below the split-context bins that launch also begins with THIS layer's attention and
+ * output projection (llama2_q4.cu:320-323) -- half of its blocks run the attention role's (head, V slice) units, the other half the output
+ * projection; the whole layer behind its q / k / v is ONE launch, 1 launch/layer; bit-identical to levels 3 / 4 / 5. */
 void q4_set_fusion(int level);
 int q4_get_fusion(void);
 /* 1: at fusion levels 4 / 5 a layer's FFN half of these sizes runs as one launch on the current device and stream (csrc/gemv_ffn_pair.h) */

@@ -50,11 +50,18 @@ struct AttArgs {
 // form's, only the fp32 order in which an output sums its positions differs (16 positions per instruction instead of 4).
 // LB: positions the caller guarantees to exist whatever the position word says (bin 256 is entered at position 128): their K
 // rows are requested BEFORE the word has arrived -- 0.19 us of dependent latency off half of the K stream
-template <int LPR, int U, int NW, int FUSED, bool PAD = false, int VS = 1, int LB = 0>
-__device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho, const int vs = 0) {
+// VW (V-slice form): waves that take part in the P.V pass and whose partials the output sums. A sixteen-wave caller (the whole-layer launch,
+// gemv_ffn_pair.h) passes 8: scores and statistics do not depend on the wave count, and with the P.V pass on eight waves every output adds the
+// terms of the eight-wave role in the same order -- bit for bit the same head.
+// lds_off: where the body's scratch (32 + NW * head_size + lds_scores floats) begins in the block's dynamic LDS; hook(): called once every K / V
+// request of the first group is out (a caller with other streams to start puts them behind these).
+struct AttNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int LPR, int U, int NW, int FUSED, bool PAD = false, int VS = 1, int LB = 0, int VW = NW, typename HOOK = AttNoHook>
+__device__ __forceinline__ void attention_body(const AttArgs& a, const int h, const Handoff& ho, const int vs = 0, const unsigned lds_off = 0u, const HOOK hook = HOOK{}) {
     static_assert(!PAD || !FUSED, "padded heads: stand-alone kernel only");
-    static_assert(VS == 1 || (FUSED && LPR == 4 * VS && (U * (64 / LPR)) % 16 == 0), "V slices: fused role, 64-byte slices, whole wave instructions");
-    constexpr int UV = VS > 1 ? U * (64 / LPR) / 16 : U;   // V-slice form: wave instructions per pass (16 positions each)
+    static_assert(VS == 1 || (FUSED && LPR == 4 * VS && (U * NW * (64 / LPR)) % (VW * 16) == 0), "V slices: fused role, 64-byte slices, whole wave instructions");
+    static_assert(VW == NW || VS > 1, "fewer P.V waves: V-slice form only");
+    constexpr int UV = VS > 1 ? U * NW * (64 / LPR) / (VW * 16) : U;   // V-slice form: wave instructions per pass (16 positions each)
     constexpr int R = 64 / LPR;            // positions per wave instruction
     constexpr bool PUB = FUSED != 0;
 #ifdef Q4_PROFILING
@@ -65,7 +72,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiling stamps (dbg != nullptr only)
     if (STAMPS && a.dbg) ts[0] = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red_max = reinterpret_cast<float*>(smem);         // [16]
+    float* red_max = reinterpret_cast<float*>(smem + lds_off);   // [16]
     float* red_sum = red_max + 16;                           // [16]
     float* outp = red_sum + 16;                              // [NW][head_size] output partials
     float* sc = outp + NW * a.head_size;                     // [lds_scores] scores, then exps
@@ -123,15 +130,18 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (VS > 1) {      // lane = (position lane >> 2 of 16, 16-byte piece lane & 3 of the block's 64-byte slice)
         const unsigned slice_off = ((unsigned)(h / a.kv_mul) * (unsigned)head_size + (unsigned)vs * 32u + (lane & 3u) * 8u) * 2u;
+        // (waves past VW aim beyond the descriptor's range: zeros, no memory request, no branch around a load)
+        const bool vwave = VW == NW || wave < VW;
 #pragma unroll
         for (int u = 0; u < UV; u++)
-            vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * 16 + (int)(lane >> 2) + u * NW * 16) * row_bytes + slice_off, 0, 0);
+            vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, vwave ? (unsigned)(wave * 16 + (int)(lane >> 2) + u * VW * 16) * row_bytes + slice_off : 0xFFFFFF00u, 0, 0);
     } else {
 #pragma unroll
         for (int u = 0; u < U; u++)
             vv0[u] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)(wave * R + row + u * stride) * row_bytes + lane_off, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    hook();
 
     // ---- pass 1: scores (loop bounds are wave-uniform so DPP row sums always see full rows) ----------
     float wmax = -INFINITY;
@@ -195,8 +205,8 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
         // (the fused role never has more than one register-resident group: size <= the bin = `group`)
 #pragma unroll
         for (int u = 0; u < UV; u++) {
-            const int t = wave * 16 + (int)(lane >> 2) + u * NW * 16;
-            const float p = t < size ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
+            const int t = wave * 16 + (int)(lane >> 2) + u * VW * 16;
+            const float p = t < size && (VW == NW || wave < VW) ? round_h(sc[t] * inv_sum) : 0.f;            // gpu_kernels.h:400
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const h2 v2 = as_h2(vv0[u][e]);
@@ -210,7 +220,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
         float s1 = swap16_add(swap32_add(acc[4], acc[6]), swap32_add(acc[5], acc[7]));
         s0 += dpp_mov<0x128>(s0); s0 += dpp_mov<0x124>(s0);                       // row_ror:8, row_ror:4
         s1 += dpp_mov<0x128>(s1); s1 += dpp_mov<0x124>(s1);
-        if ((lane & 12u) == 0u) {
+        if ((lane & 12u) == 0u && (VW == NW || wave < VW)) {
             outp[wave * 32 + (lane & 3u) * 8 + (lane >> 4)] = s0;
             outp[wave * 32 + (lane & 3u) * 8 + 4 + (lane >> 4)] = s1;
         }
@@ -274,12 +284,12 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int n = g * 2 + k;
-                float part[NW];
+                float part[VW];
 #pragma unroll
-                for (int w = 0; w < NW; w++) part[w] = VS > 1 ? outp[w * 32 + (int)tid * 2 + k] : outp[w * head_size + n];
+                for (int w = 0; w < VW; w++) part[w] = VS > 1 ? outp[w * 32 + (int)tid * 2 + k] : outp[w * head_size + n];
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; w++) s += part[w];
+                for (int w = 0; w < VW; w++) s += part[w];
                 s2[k] = s;
             }
             const h2 hh = {(f16_t)s2[0], (f16_t)s2[1]};

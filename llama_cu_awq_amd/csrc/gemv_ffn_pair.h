@@ -22,7 +22,9 @@
 // consumer second, producers wait for nobody, so the launch cannot wedge while all blocks are resident (grid = CUs of the device, the stream unmasked:
 // ffn_pair_covers); every wait is bounded and a run-out sets the model's sticky error word (q4_handoff_status: one clean retry at fusion level 1).
 #pragma once
+#include <type_traits>
 #include "gemv_strip.h"
+#include "attention.h"
 
 namespace q4 {
 
@@ -55,6 +57,16 @@ struct QkvNextArgs {
     unsigned ppb;              // RoPE pairs (i, i + head_size / 2) per block and matrix: dim / 2 / blocks (8)
 };
 
+// phases A and O (fusion level 6, template ATT): MultiHeadAttention and the output projection with its residual add of THIS layer (llama2_q4.cu:320-323) in front
+// of phase 1 -- the launch is then the whole layer behind its q / k / v, and with QKV the next layer's q / k / v as well
+struct LayerAttArgs {
+    AttArgs att;               // output = RunState::xb, q, this layer's cache rows, the bin
+    GemvMat o;                 // the output projection's tensors (K = N = dim = 4096)
+    u32x2v* agran;             // dim / 2 granules {xb[2 g], xb[2 g + 1], tag}: the attention output between phases A and O
+    u32x2v* xogran;            // dim / 2 granules of the residual stream between phases O and 1
+    unsigned nheads, natt;     // heads; blocks [0, natt) run a (head, V slice) unit of the attention (natt = 4 x heads <= blocks)
+};
+
 constexpr int FP_ROWS = 6;             // 64-unit rows of the staged hb vector: hidden <= 12288
 constexpr int FP_NC2MAX = 16;          // down projection columns per block
 struct FfnPairLds {
@@ -71,23 +83,35 @@ struct FfnPairLds {
     static constexpr unsigned QSIDE_Z = QSIDE_S + 3072u;            // 1 KiB: 48 columns x 4 words x 4 B
     static constexpr unsigned STAMP2 = QSIDE_Z + 1024u;             // profiling build: [64] more stamps ([0..15] phase 2 done per wave, [16..31] phase 3 done per wave, [32..] the second seam)
     static constexpr unsigned BYTES = STAMP2 + 512u;
-    // phase 3's x chain re-uses phase 1's (dead since barrier A, clear of the staged hb vector): G::XS, G::SX, G::PART; its column totals: G::TOT
+    // phases A / O (fusion level 6), before phase 1: the attention role's scratch lies over the x staging area; the DW region takes what is requested AHEAD of
+    // phase 1 -- three gate/up pieces a wave (pieces 2 .. 4) where the down columns 0 .. 7 will land (and behind the last column where they do not fit there), and the down
+    // projection's columns 8 .. 15 in their final place; [TOT2 + 128, + 32): the residual of the block's down columns
+    static constexpr unsigned ATT_LDS = G::XS;                     // (32 + 16 x 128 + 256) floats <= XS .. TOT
+    static constexpr int NCREDIT = 3;
+    // 1 KiB entry k = 16 (piece - 2) + wave of the pieces ahead: below the down columns 8 .. 15 where it fits, behind them otherwise
+    static __host__ __device__ constexpr unsigned credit_slot(unsigned k, unsigned colbytes2) {
+        const unsigned lowcap = (8u * colbytes2) >> 10, tail0 = (16u * colbytes2 + 1023u) >> 10;
+        return DW + (k < lowcap ? k : tail0 + (k - lowcap)) * 1024u;
+    }
+    static __host__ __device__ constexpr bool credit_fits(unsigned colbytes2) { return credit_slot(16u * NCREDIT - 1u, colbytes2) + 1024u <= DW + DW_BYTES; }
 };
 static_assert(FfnPairLds::BYTES <= 160 * 1024, "one block per CU");
+static_assert((32 + 16 * 128 + 256) * 4 <= FfnPairLds::G::STAMP - FfnPairLds::G::XS, "phase A / O layout");
 static_assert(FfnPairLds::QSIDE_S % 16 == 0, "alignment");
 static_assert(FfnPairLds::DW % 16 == 0 && FfnPairLds::TOT2 % 16 == 0, "alignment");
 constexpr unsigned FP_POLL_LIMIT = 1u << 18;    // gather passes without a down piece in between (each a memory round trip + s_sleep): ~0.3 s, then give up
 
 #define FPSTAMP(k) do { if (STAMPS && lane == 0) st[(k)] = wall_clock64(); } while (0)
 #define FPSTAMP2(k) do { if (STAMPS && lane == 0) reinterpret_cast<unsigned long long*>(smem + P::STAMP2)[(k)] = wall_clock64(); } while (0)
-template <bool NORM, bool STAMPS, bool QKV = false>
+template <bool NORM, bool STAMPS, bool QKV = false, int ATT = 0>
 __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4* __restrict__ arg_x, const u32x4* __restrict__ arg_rms, const void* arg_w0, const void* arg_w1, const unsigned wbytes,
-                                                                    const unsigned pbase, const unsigned prem, const GemvArgs a, const FfnPairArgs p, const QkvNextArgs q3) {
+                                                                    const unsigned pbase, const unsigned prem, const GemvArgs a, const FfnPairArgs p, const QkvNextArgs q3, const LayerAttArgs la) {
     constexpr int TS = 2, D = 2;
     constexpr unsigned CB = 2048u, G = 32u, ZW = 4u;
     constexpr int NSTAGE = 8;
     using L = StripLds<D, TS>;
     using P = FfnPairLds;
+    static_assert(!ATT || NORM, "whole-layer form: the FFN half normalises");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,8 +133,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                                                                   // [12] passes; per wave: [16 + w] gathered, [32 + w] gate/up done, [48 + w] down pieces landed
 
     // ---- entry, as ffn_strip_kernel: x first, then the hand-off word, the side data of both phases, then the ring
+    // (whole-layer form: x does not exist yet -- the attention role's rows first, or nothing in front of the o-proj weights)
     u32x4 xraw = {0u, 0u, 0u, 0u}, wraw = {0u, 0u, 0u, 0u};
-    if (stager) {
+    if (!ATT && stager) {
         const u32x4* px = arg_x + tid;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xraw) : "v"(px) : "memory");
         if (NORM) {
@@ -119,36 +144,48 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         }
     }
     unsigned resid_raw = 0u;                             // the residual of this block's down columns (wave 0): x is not rewritten before the launch's last instruction
-    if (wave == 0) {
-        const q4_half* pr = p.xio + c0d + (lane < (unsigned)nc2 ? lane : 0u);
-        asm volatile("global_load_ushort %0, %1, off" : "=&v"(resid_raw) : "v"(pr) : "memory");
-    }
     u32x2v ee = {0u, 0u};                                // [0] the error word, [1] the epoch = this launch's tag (advanced by the fused QKV launch in front: >= 1)
-    {
+    if constexpr (ATT != 0) {
+        // a load the compiler sees (it places the wait at the first use -- the attention role's publishing store, the poll): an asm load would have to be
+        // waited for by hand in front of the role's own requests
+        unsigned zero_off = 0;
+        asm volatile("" : "+v"(zero_off));
+        ee = load_granule(reinterpret_cast<const u32x2v*>(p.sync), zero_off);
+    } else {
+        if (wave == 0) {
+            const q4_half* pr = p.xio + c0d + (lane < (unsigned)nc2 ? lane : 0u);
+            asm volatile("global_load_ushort %0, %1, off" : "=&v"(resid_raw) : "v"(pr) : "memory");
+        }
         const unsigned* pe = p.sync;
         asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(ee) : "v"(pe) : "memory");
     }
     constexpr int NSIDE = (int)(L::NS_S + L::NS_Z);      // 5 side pieces per gate/up matrix
-    if (wave < 2 * NSIDE) {
-        const int m = wave >= NSIDE, q = wave - NSIDE * m;
-        if (q < (int)L::NS_S) {
-            const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[m].s, c0 * (G * 2u), (unsigned)(a.N * a.sh * 2));
-            dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
-        } else {
-            const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[m].z, c0 * (ZW * 4u), (unsigned)(a.N * a.pzh * 4));
-            dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (q - (int)L::NS_S) * 1024u, voff + (unsigned)(q - (int)L::NS_S) * 1024u, rz, 0u);
+    auto issue_sides_of = [&](const int wave) {          // the side piece wave `wave` is in charge of (a wave may stand in for another one)
+        if (wave < 2 * NSIDE) {
+            const int m = wave >= NSIDE, q = wave - NSIDE * m;
+            if (q < (int)L::NS_S) {
+                const __amdgpu_buffer_rsrc_t rs = rsrc_from(a.m[m].s, c0 * (G * 2u), (unsigned)(a.N * a.sh * 2));
+                dma_piece_default(L::SIDE_S + m * L::SIDE_S_BYTES + q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
+            } else {
+                const __amdgpu_buffer_rsrc_t rz = rsrc_from(a.m[m].z, c0 * (ZW * 4u), (unsigned)(a.N * a.pzh * 4));
+                dma_piece_default(L::SIDE_Z + m * L::SIDE_Z_BYTES + (q - (int)L::NS_S) * 1024u, voff + (unsigned)(q - (int)L::NS_S) * 1024u, rz, 0u);
+            }
+        } else if (wave < 2 * NSIDE + 4) {                   // the down projection's scales (three pieces) and zeros (one) of this block's columns
+            const int q = wave - 2 * NSIDE;
+            if (q < 3) {
+                const __amdgpu_buffer_rsrc_t rs = rsrc_from(p.d.s, c0d * (unsigned)p.sh * 2u, (unsigned)(p.Nd * p.sh * 2));
+                dma_piece_default(P::DSIDE_S + (unsigned)q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
+            } else {
+                const __amdgpu_buffer_rsrc_t rz = rsrc_from(p.d.z, c0d * (unsigned)p.pzh * 4u, (unsigned)(p.Nd * p.pzh * 4));
+                dma_piece_default(P::DSIDE_Z, voff, rz, 0u);
+            }
         }
-    } else if (wave < 2 * NSIDE + 4) {                   // the down projection's scales (three pieces) and zeros (one) of this block's columns
-        const int q = wave - 2 * NSIDE;
-        if (q < 3) {
-            const __amdgpu_buffer_rsrc_t rs = rsrc_from(p.d.s, c0d * (unsigned)p.sh * 2u, (unsigned)(p.Nd * p.sh * 2));
-            dma_piece_default(P::DSIDE_S + (unsigned)q * 1024u, voff + (unsigned)q * 1024u, rs, 0u);
-        } else {
-            const __amdgpu_buffer_rsrc_t rz = rsrc_from(p.d.z, c0d * (unsigned)p.pzh * 4u, (unsigned)(p.Nd * p.pzh * 4));
-            dma_piece_default(P::DSIDE_Z, voff, rz, 0u);
-        }
+    };
+    auto issue_sides = [&]() { issue_sides_of(wave); };
+    if (!ATT) {
+        issue_sides();
+        block_barrier_lds();  // the x loads are queued on this CU in front of every weight piece (the path returns in order)
     }
-    block_barrier_lds();      // the x loads are queued on this CU in front of every weight piece (the path returns in order)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(mat ? arg_w1 : arg_w0), 0, (int)wbytes, 0x00020000);
     const unsigned ring = L::RING + (unsigned)wave * (D * 1024u);
     const unsigned soff0 = (c0 + ((unsigned)gw >> 1)) * CB;
@@ -172,16 +209,187 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         if (64u * ks + lane < ku && ubase + 64u * ks + lane < uend) dma_piece(P::DW + first * 16u, voff, rd, first * 16u);
     };
     const int nstream = npieces + ndp;
+    auto prime_ring = [&]() {
 #pragma unroll
-    for (int k = 0; k < D; k++)
-        if (k < npieces) issue2(k / TS, k % TS);
+        for (int k = 0; k < D; k++)
+            if (k < npieces) issue2(k / TS, k % TS);
+    };
+    if (!ATT) prime_ring();
 
-    // ---- x chain (ffn_strip_kernel's)
     u32x4* xs = reinterpret_cast<u32x4*>(smem + L::XS);
     float* sx = reinterpret_cast<float*>(smem + L::SX);
     float* part = reinterpret_cast<float*>(smem + L::PART);
     float* tot = reinterpret_cast<float*>(smem + L::TOT);
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xraw), "+v"(wraw), "+v"(ee), "+v"(resid_raw) : "n"(D) : "memory");   // all but the weight pieces (every wave has units: ffn_pair_covers)
+    if constexpr (ATT != 0) {
+        // ---- phases A and O. Blocks [0, natt) -- half of the launch -- run one (head, V slice) unit of the attention each: attention_oproj_kernel's role
+        // (layer_attn.h, forms 5 / 6) on sixteen waves; scores and softmax statistics do not depend on the wave count, the P.V pass stays on eight waves, so every
+        // output sums the same terms in the same order. The other half are the output projection: 32 columns a block, two a wave, weights in registers since
+        // entry -- gemv_q4_kernel<MODE_PLAIN, 2, 2, false, 5, 1>'s arithmetic (the o-proj role). Either half then has nothing to do until x exists: it requests
+        // its side data, its ring and SIX more gate/up pieces a wave (units 1 .. 3) into the region the down weights will take later -- HBM has little else to
+        // do in these phases, and 8 of a wave's 10 .. 12 pieces are in LDS when phase 1 begins.
+        const bool att_block = blockIdx.x < la.natt;
+        const unsigned jb = blockIdx.x - la.natt;              // o-proj block: columns [32 jb, 32 jb + 32)
+        // everything wave w wants in LDS when phase 1 begins, requested by this wave (w = wave, or a wave of the same parity -- same matrix, same k-part -- that
+        // must not queue requests now): its side piece, its ring's first two pieces, pieces 2 .. 4 ahead, its three pieces of the down columns 8 .. 15
+        auto issue_ahead_of = [&](const int w) {
+            issue_sides_of(w);
+            const unsigned so = (c0 + ((unsigned)w >> 1)) * CB;
+#pragma unroll
+            for (int j = 0; j < 2 + P::NCREDIT; j++) {
+                const unsigned dst = j < 2 ? L::RING + (unsigned)w * (D * 1024u) + (unsigned)j * 1024u : P::credit_slot(16u * (unsigned)(j - 2) + (unsigned)w, colbytes2);
+                dma_piece(dst, voff, rw, so + (unsigned)(j / TS) * (8u * CB) + (unsigned)(j % TS) * 1024u);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const unsigned first = (((unsigned)w >> 1) + 8u) * (unsigned)p.pw4 + ubase + 64u * (unsigned)ks;
+                if (64u * (unsigned)ks + lane < ku && ubase + 64u * (unsigned)ks + lane < uend) dma_piece(P::DW + first * 16u, voff, rd, first * 16u);
+            }
+        };
+        const unsigned tagA = ee[1];            // raw (arithmetic on it here would pull the load's wait in front of the role's requests): tag_add is 0 in this form
+        const unsigned nchA = (unsigned)a.K >> 3;                          // 512 chunks of eight halves: one per thread of waves 0 .. 7
+        const bool gathA = tid < nchA;
+        unsigned deadA = 0u;
+        auto gather_vec = [&](const u32x2v* gran, u32x4& out, u32x4& other) {      // other: an asm load of the caller that lands under the pass
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(nchA * 32u), 0x00020000);
+            bool need = true, failed = false;
+            unsigned tries = 0;
+            for (;;) {
+                u32x4 g0, g1;
+                const unsigned o0 = need ? tid * 32u : 0x7FFFFF00u;
+                // (sc1: past the L1; see the third phase's gather)
+                asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1" : "=&v"(g0), "=&v"(g1) : "v"(o0), "s"(rg) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(g0), "+v"(g1), "+v"(other) : : "memory");
+                if (need && g0[1] == tagA && g0[3] == tagA && g1[1] == tagA && g1[3] == tagA) { out = (u32x4){g0[0], g0[2], g1[0], g1[2]}; need = false; }
+                if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+                if (++tries >= FP_POLL_LIMIT || deadA != 0u) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed && deadA == 0u && lane == 0) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (att_block) {
+            Handoff ho = {};
+            ho.tag = tagA;
+            ho.pub = la.agran;
+#ifdef Q4_PROFILING
+            ho.mute = p.mute != 0;
+#endif
+            constexpr int UA = ATT == 1 ? 2 : 4;
+            attention_body<16, UA, STRIP_WAVES, 2, false, 4, ATT == 2 ? 128 : 0, 8>(la.att, (int)(blockIdx.x % la.nheads), ho, (int)(blockIdx.x / la.nheads), P::ATT_LDS);
+            if (wave == 0) FPSTAMP2(40);
+            block_barrier_lds();                           // the role's scratch lies over the x staging area
+            issue_ahead_of(wave);
+            deadA = ee[0];
+        } else {
+            // the o-proj block's requests, all at entry: two columns a wave with their zero words and scales (as gemv_q4.h loads them), the residual
+            const unsigned col0 = 32u * jb + 2u * (unsigned)wave;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)la.o.w, 0, a.K * 2048, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)la.o.z, 0, a.K * 16, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)la.o.s, 0, a.K * 64, 0x00020000);
+            u32x4 ow[2][2];
+            unsigned ozw[2][2];
+            uint16_t osc[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const unsigned jj = 64u * (unsigned)ks + lane;
+                    ozw[c][ks] = __builtin_amdgcn_raw_buffer_load_b32(rz, (jj >> 5) * 4u, (col0 + (unsigned)c) * 16u, 0);
+                    osc[c][ks] = __builtin_amdgcn_raw_buffer_load_b16(rs, (jj >> 2) * 2u, (col0 + (unsigned)c) * 64u, 0);
+                    ow[c][ks] = __builtin_amdgcn_raw_buffer_load_b128(ro, jj * 16u, (col0 + (unsigned)c) * 2048u, 2);
+                }
+            unsigned ores = 0u;
+            if (tid < 32u) ores = reinterpret_cast<const uint16_t*>(p.xio)[32u * jb + tid];     // the o-proj's residual (:323, accum)
+            __builtin_amdgcn_sched_barrier(0);
+            // waves 8 .. 15 (they do not gather) request what they want ahead of phase 1 now: landed before the attention output exists. Waves 0 .. 7 wait until
+            // the block has published: requests of theirs in front of the gather would delay it (the CU's path returns in order). (All of it by waves 8 .. 15 at
+            // entry, for both halves of the block, was measured: the bytes then sit in front of the gather all the same -- 1001 -> 978 tokens/s.)
+            if (wave >= NSTAGE) issue_ahead_of(wave);
+            if (wave == 0) FPSTAMP2(40);
+            deadA = ee[0];
+            // ---- seam A -> O: one lane polls ONE granule (the last of head jb % heads: few pollers per line), then waves 0 .. 7 read the vector, every granule
+            // validating itself (layer_attn.h's protocol)
+            if (tid == 0 && deadA == 0u) {
+                const unsigned sentinel = (jb % la.nheads) * ((unsigned)la.att.head_size >> 1) + ((unsigned)la.att.head_size >> 1) - 1u;
+                unsigned i = 0;
+                while (load_granule(la.agran, sentinel)[1] != tagA && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
+                if (i >= POLL_LIMIT) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            block_barrier_lds();
+            if (gathA) {
+                u32x4 av = {0u, 0u, 0u, 0u};
+                gather_vec(la.agran, av, wraw);
+                // stage: gemv_q4_body's layout for a vector that is multiplied as it is (odd units negated)
+                const unsigned sgn = q4_stage_sign_bits(tid);
+                const u32x4 pv = permute_x8(q4_signed_x(av, sgn));
+                const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+                float cb = 0.f;
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+                cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+                const unsigned j = tid >> 2, d = tid & 3u;
+                xs[(((j >> 6) * 4 + d) << 6) + (j & 63u)] = pv;
+                if (d == 0) sx[j] = cb * -9.5367431640625e-07f;
+            }
+            block_barrier_lds();
+            if (wave == 0) FPSTAMP2(41);
+            float cso[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                u32x4 X[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) X[d] = xs[((ks * 4 + d) << 6) + lane];
+                const float corr = sx[ks * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const u32x4 w = ow[c][ks];
+                    float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned ww = w[d], tt = ww >> 8;
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[d][0]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[d][1]), acc_o, false);
+                        acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][2]), acc_e, false);
+                        acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][3]), acc_o, false);
+                    }
+                    const float zf = (float)((ozw[c][ks] >> (((lane >> 2) & 7u) * 4u)) & 0xFu);
+                    float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+                    t = __builtin_fmaf(zf, corr, t);
+                    cso[c] = __builtin_fmaf(h2f(osc[c][ks]), t, cso[c]);
+                }
+            }
+            const float total = reduce4_q4(cso[0], cso[1], 0.f, 0.f) * 1048576.f;      // rows 0 and 1 hold the two columns
+            float* totO = reinterpret_cast<float*>(smem + P::TOT2);
+            if ((lane & 15u) == 0u && (lane >> 4) < 2u) totO[2 * wave + (int)(lane >> 4)] = total;
+            block_barrier_lds();
+            if (wave == 0) {
+                uint16_t xo = 0;
+                if (lane < 32u) {
+                    float r = totO[lane];
+                    r += h2f((uint16_t)ores);                   // gpu_kernels.h:229-230
+                    xo = f2h(r);                                // :231 -- as granules only: RunState::x is written once per launch, by the block that owns the
+                }                                               // column in phase 2 (two CUs' plain stores to one line may be written back in either order)
+                const unsigned partner = (unsigned)__shfl_down((int)xo, 1);
+                if ((lane & 1u) == 0u && lane < 32u) store_granule(la.xogran + ((32u * jb + lane) >> 1), (unsigned)xo | (partner << 16), tagA);
+                FPSTAMP2(42);
+            }
+            if (wave < NSTAGE) issue_ahead_of(wave);
+        }
+        // ---- seam O -> 1: the residual stream from every o-proj block, the x chain of the FFN half (ffn_strip_kernel's: 512 chunk partials, canonical reduction)
+        if (gathA) {
+            const u32x4* pw = arg_rms + tid;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
+            gather_vec(la.xogran, xraw, wraw);
+            // the residual of the block's sixteen down columns (chunks 2 b and 2 b + 1): kept in LDS until phase 2 ends
+            if ((tid >> 1) == blockIdx.x) *reinterpret_cast<u32x4*>(smem + P::TOT2 + 128u + (tid & 1u) * 16u) = xraw;
+        }
+        wait_vmcnt<0>();                                   // the side data, the pieces ahead and the ring's first pieces have landed (phase 1 counts from here)
+        if (wave == 1) FPSTAMP2(43);
+    } else {
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xraw), "+v"(wraw), "+v"(ee), "+v"(resid_raw) : "n"(D) : "memory");   // all but the weight pieces (every wave has units: ffn_pair_covers)
+    }
+
+    // ---- x chain (ffn_strip_kernel's)
     if (wave == 0) FPSTAMP(1);
     if (NORM) {
         if (tid < (unsigned)(TS * 256)) part[tid] = stager ? sumsq8(xraw, 0.f) : 0.f;
@@ -221,7 +429,14 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const unsigned char* zbase = smem + L::SIDE_Z + mat * L::SIDE_Z_BYTES + ((unsigned)(gw >> 1) * ZW + (lane >> 5)) * 4u;
         const unsigned zsh = ((lane >> 2) & 7u) * 4u;
 
-        for (int g4 = 0; g4 * 4 < nu; g4++) {
+        // Whole-layer form. Pieces 0, 1 wait in the ring, 2 .. 4 in the region ahead, the rest stream through the ring again (piece j >= 5 in entry (j + 1) % 2: the
+        // entry pieces 0 and 1 free). The down columns 8 .. 15 are in LDS already; 0 .. 7 go out as soon as every wave has left the region ahead (a barrier
+        // behind piece 4). Requests of a wave in phase 1, in order: G5 G6 | d0 d1 | G7 d2 | G8 | G9 | G10 ...; the waits below count the younger ones.
+        auto issue2s = [&](const int j, const int entry) {
+            dma_piece(ring + (unsigned)entry * 1024u, voff, rw, soff0 + (unsigned)(j / TS) * (8u * CB) + (unsigned)(j % TS) * 1024u);
+        };
+        auto group = [&](auto first_c, const int g4) {
+            constexpr bool CRED = ATT != 0 && decltype(first_c)::value;
             float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -232,13 +447,38 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                     for (int ks = 0; ks < TS; ks++) {
                         const int j = TS * i + ks;
                         const int e = (TS * r + ks) & (D - 1);
-                        if (j + 1 < nstream) wait_vmcnt<D - 1>(); else wait_vmcnt<0>();     // piece j has landed
-                        const u32x4 w = *reinterpret_cast<const u32x4*>(wbase + e * 1024);
+                        const unsigned char* wsrc = wbase + e * 1024;
+                        const int jj = TS * r + ks;         // a constant once unrolled
+                        if constexpr (CRED) {
+                            if (jj >= 2 && jj <= 4) wsrc = smem + P::credit_slot(16u * (unsigned)(jj - 2) + (unsigned)wave, colbytes2) + lane * 16u;   // (landed before phase 1 began)
+                            else if (jj >= 5) wsrc = wbase + ((jj + 1) & 1) * 1024;
+                            if (jj == 5) wait_vmcnt<3>(); else if (jj == 6) wait_vmcnt<4>(); else if (jj == 7) wait_vmcnt<2>();
+                        } else if constexpr (ATT != 0) {
+                            wsrc = wbase + ((jj + 1) & 1) * 1024;
+                            if (j + 1 < npieces) wait_vmcnt<1>(); else wait_vmcnt<0>();
+                        } else {
+                            if (j + 1 < nstream) wait_vmcnt<D - 1>(); else wait_vmcnt<0>();     // piece j has landed
+                        }
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(wsrc);
                         const uint16_t sc = *reinterpret_cast<const uint16_t*>(sbase + (unsigned)i * (8u * G * 2u) + ks * 32);
                         const unsigned zw = *reinterpret_cast<const unsigned*>(zbase + (unsigned)i * (8u * ZW * 4u) + ks * 8);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done: the entry may be refilled
-                        if (j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
-                        else if (j + D < nstream) issue_down(j + D - npieces);                // ... and behind the last gate/up piece the stream goes on
+                        if constexpr (CRED) {
+                            if (jj < 2) issue2s(jj + 5, jj);
+                            if (jj == 4) {
+                                block_barrier_lds();       // every wave has left the region ahead
+                                if (0 < ndp) issue_down(0);
+                                if (1 < ndp) issue_down(1);
+                            }
+                            if (jj == 5) { issue2s(7, 0); if (2 < ndp) issue_down(2); }
+                            if (jj == 6) issue2s(8, 1);
+                            if (jj == 7) issue2s(9, 0);
+                        } else if constexpr (ATT != 0) {
+                            if (j + 2 < npieces) issue2s(j + 2, (jj + 1) & 1);
+                        } else {
+                            if (j + D < npieces) issue2(i + (ks + D) / TS, (ks + D) % TS);
+                            else if (j + D < nstream) issue_down(j + D - npieces);                // ... and behind the last gate/up piece the stream goes on
+                        }
                         float acc_e = 0.f, acc_o = 0.f;
 #pragma unroll
                         for (int d = 0; d < 4; d++) {
@@ -260,10 +500,17 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             const float total = reduce4_q4(cs[0], cs[1], cs[2], cs[3]) * 1048576.f;
             const int row = lane >> 4;
             if ((lane & 15u) == 0 && g4 * 4 + row < nu) tot[gw + 16 * (g4 * 4 + row)] = total;   // [column][matrix] = unit index
+        };
+        if constexpr (ATT != 0) {
+            group(std::true_type{}, 0);
+            for (int g4 = 1; g4 * 4 < nu; g4++) group(std::false_type{}, g4);
+        } else {
+            for (int g4 = 0; g4 * 4 < nu; g4++) group(std::false_type{}, g4);
         }
     }
     FPSTAMP(32 + wave);
     int rnext = ndp < D ? ndp : D;                     // down pieces this wave has requested so far
+    if (ATT != 0) rnext = ndp;                         // (whole-layer form: all of them)
     block_barrier_lds();                               // barrier A: the block's gate/up totals are in LDS, its rings are dead
 
     // ---- the seam
@@ -476,7 +723,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         if ((int)tid < nc2) {
             float r = tot2[2 * tid];
             r += tot2[2 * tid + 1];                     // fixed order: k-parts from the lowest up
-            r += h2f(resid);                            // gpu_kernels.h:229-230
+            r += h2f(ATT != 0 ? reinterpret_cast<const uint16_t*>(smem + P::TOT2 + 128u)[tid] : resid);   // gpu_kernels.h:229-230
             xnew = f2h(r);
             p.xio[c0d + tid] = xnew;                    // :231
         }
@@ -524,7 +771,9 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             for (;;) {
                 u32x4 g0, g1;
                 const unsigned o0 = need ? tid * 32u : 0x7FFFFF00u;
-                // sc1 from the first pass on: the blocks reach this seam up to a microsecond apart, an early plain read would leave stale lines in the L1
+                // sc1 from the first pass on: the blocks reach this seam up to a microsecond apart, an early plain read would leave stale lines in this CU's L1 (the
+                // XCDs' L2s are kept coherent, tools/lab/t_l2stale.hip). Plain loads with the L1 invalidated in front of every retry were measured: `buffer_inv sc1`
+                // takes ~10 us a pass (1019 -> 728 tokens/s), `buffer_inv sc0` does not invalidate the L1 at all (the waits run out)
                 asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1" : "=&v"(g0), "=&v"(g1) : "v"(o0), "s"(rg) : "memory");
                 if (passes == 0) unpack3(0, 1);         // under the first pass (the third column behind it, when the pass's registers are free again)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

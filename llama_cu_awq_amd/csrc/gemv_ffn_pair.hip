@@ -1,5 +1,6 @@
 // gemv_ffn_pair.hip -- host side of the FFN half of a layer as one launch (gemv_ffn_pair.h; fusion level 4, llama2_q4.cu:326-332).
 #include "gemv_ffn_pair.h"
+#include <math.h>
 
 namespace q4 {
 
@@ -15,7 +16,19 @@ static void fill_gate_up(GemvArgs& a, int dim, int hidden) {
 
 // words the launch needs behind the model's other hand-off words: hidden / 2 granules of 8 bytes for hb, then dim / 2 for the residual stream
 // between its second and third phase (fusion level 5)
-size_t ffn_pair_sync_words(int dim, int hidden) { return (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 2; }
+// between its second and third phase (fusion level 5), then dim / 2 for the residual stream between the output projection and the FFN half (level 6)
+size_t ffn_pair_sync_words(int dim, int hidden) { return (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 4; }
+
+// fusion level 6: the launch begins with the layer's attention and output projection. Llama-2-7B's shape below the split-context bins: 128-wide heads (four
+// 64-byte V slices each), as many (head, slice) units as half the blocks -- the other half are the output projection, 32 columns of two k-slots each; the attention's arithmetic is
+// the V-slice role's of layer_attn.h (forms 5 / 6), which q4_runtime.hip checks is what fusion level 3 would run
+bool layer_att_covers(int dim, int hidden, int kv_dim, int n_heads, int seq_len_bin) {
+    if (!ffn_pair_covers(dim, hidden) || n_heads < 1 || dim % n_heads || kv_dim != dim) return false;
+    const int nb = cu_count(), head_size = dim / n_heads;
+    // (every wave then has ten gate/up pieces or more; the pieces requested ahead fit around the down columns 8 .. 15)
+    if (!FfnPairLds::credit_fits((unsigned)make_geom(hidden, dim).pw4 * 16u)) return false;
+    return dim == 4096 && head_size == 128 && n_heads * 8 == nb && dim == 16 * nb && seq_len_bin <= 256 && g_ao_vslice != 0 && (hidden / 2) / nb >= 20;
+}
 
 // fusion level 5: the launch also runs rmsnorm + q/k/v + RoPE + KV write of the NEXT layer. Multi-head models with 128-wide heads and a rotation table
 // (every Llama-2-7B-shaped model): a block's eight RoPE pairs stay inside one head.
@@ -38,16 +51,21 @@ bool ffn_pair_covers(int dim, int hidden) {
 int ffn_pair_prepare() {
     int rc = lds_opt_in((const void*)ffn_pair_kernel<true, false>, FfnPairLds::BYTES);
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true, 1>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true, 2>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, false, 1>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, false, 2>, FfnPairLds::BYTES);
 #ifdef Q4_PROFILING
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true>, FfnPairLds::BYTES);
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true>, FfnPairLds::BYTES);
-
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true, 1>, FfnPairLds::BYTES);
+    if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true, 2>, FfnPairLds::BYTES);
 #endif
     return rc;
 }
 
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word, unsigned tag_add, const FfnQkvNext* next) {
+                    unsigned* sync, size_t gran_word, unsigned tag_add, const FfnQkvNext* next, const FfnLayerAtt* att) {
     if (!rms_w || !sync || !ffn_pair_covers(dim, hidden)) return Q4_ERR_UNSUPPORTED_SIZE;
     { const int rc = ffn_pair_prepare(); if (rc) return rc; }
     GemvArgs a = {};
@@ -76,15 +94,31 @@ int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight
         q3.xgran = reinterpret_cast<u32x2v*>(sync + gran_word + (size_t)(hidden / 2) * 2);
         q3.bump = next->bump; q3.head_size = head_size; q3.kv_dim = kv_dim; q3.ppb = (unsigned)(dim / 2) / nb;
     }
+    LayerAttArgs la = {};
+    if (att) {
+        if (tag_add != 0u || !layer_att_covers(dim, hidden, att->kv_dim, att->n_heads, att->seq_len_bin)) return Q4_ERR_UNSUPPORTED_SIZE;
+        const int head_size = dim / att->n_heads;
+        la.att = {att->xb, att->q, att->kc, att->vc, head_size, dim / att->kv_dim, att->kv_dim, att->pPos, (float)(1.0 / sqrt((double)head_size)), att->seq_len_bin, nullptr};
+        fill_mat(la.o, att->wo);
+        la.agran = reinterpret_cast<u32x2v*>(sync + SYNC_GRANULES);
+        la.xogran = reinterpret_cast<u32x2v*>(sync + gran_word + (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 2);
+        la.nheads = (unsigned)att->n_heads; la.natt = 4u * (unsigned)att->n_heads;
+    }
     const unsigned pairs = (unsigned)hidden / 2u;
 #define FP_GO(...) do { Q4_LAUNCH((ffn_pair_kernel<__VA_ARGS__>), dim3(nb), dim3(STRIP_WAVES * 64), FfnPairLds::BYTES, reinterpret_cast<const u32x4*>(a.x), reinterpret_cast<const u32x4*>(a.rms_w), \
-                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p, q3); Q4_LAUNCH_CHECK(); return Q4_OK; } while (0)
+                  (const void*)a.m[0].w, (const void*)a.m[1].w, (unsigned)(a.N * a.pw4 * 16), pairs / nb, pairs % nb, a, p, q3, la); Q4_LAUNCH_CHECK(); return Q4_OK; } while (0)
 #ifdef Q4_PROFILING
     if (g_fp_mute > 0) { p.mute = 1; g_fp_mute--; }
     p.dbg = g_dbg;
-    if (g_dbg && next) FP_GO(true, true, true);
+    if (g_dbg && next && att) { if (att->seq_len_bin <= 128) FP_GO(true, true, true, 1); else FP_GO(true, true, true, 2); }
+    if (g_dbg && next && g_fusion < 6) FP_GO(true, true, true);
     if (g_dbg && g_fusion < 5) FP_GO(true, true, false);        // (at level 5 the stamps are the three-phase launches': the last layer's plain pair launch does not overwrite them)
 #endif
+    if (att) {
+        const bool b128 = att->seq_len_bin <= 128;
+        if (next) { if (b128) FP_GO(true, false, true, 1); else FP_GO(true, false, true, 2); }
+        if (b128) FP_GO(true, false, false, 1); else FP_GO(true, false, false, 2);
+    }
     if (next) FP_GO(true, false, true);
     FP_GO(true, false, false);
 #undef FP_GO

@@ -146,9 +146,15 @@ struct FfnQkvNext {
     const int* pPos; const float2* rope_table; unsigned* bump; int kv_dim, head_size;
 };
 bool ffn_qkv_covers(int dim, int hidden, int kv_dim, int head_size, bool have_rope_table);
+// ... and (fusion level 6) THIS layer's attention and output projection in front of it: the launch is the whole layer behind its q / k / v
+struct FfnLayerAtt {
+    q4_half* xb; const q4_half* q; const q4_half* kc; const q4_half* vc;     // RunState::xb, RunState::q; this layer's cache rows (layer offset applied)
+    const QWeight* wo; const int* pPos; int n_heads, kv_dim, seq_len_bin;
+};
+bool layer_att_covers(int dim, int hidden, int kv_dim, int n_heads, int seq_len_bin);
 int ffn_pair_prepare();     // gemv_ffn_pair.hip: LDS opt-in, outside any stream capture
 int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight* gate, const QWeight* up, const QWeight* down, int dim, int hidden,
-                    unsigned* sync, size_t gran_word, unsigned tag_add = 0, const FfnQkvNext* next = nullptr);
+                    unsigned* sync, size_t gran_word, unsigned tag_add = 0, const FfnQkvNext* next = nullptr, const FfnLayerAtt* att = nullptr);
 unsigned* sync_words_of_state(const RunState* s);   // q4_runtime.hip: the model's hand-off words, or null
 extern int g_fp_pre, g_fp_mute, g_fp_nt;
 

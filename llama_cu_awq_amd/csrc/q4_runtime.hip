@@ -230,7 +230,7 @@ int q4_memset(void* dst, int value, size_t bytes) {
 // o-proj as one launch on top of that (default). Level 2 (QKV -> attention -> o-proj as one launch) was measured slower than
 // level 1 in round 2 and removed in round 3: the value selects level 1.
 void q4_set_fusion(int level) {
-    g_fusion = level <= 0 ? 0 : level >= 5 ? 5 : level == 4 ? 4 : level == 3 ? 3 : 1;
+    g_fusion = level <= 0 ? 0 : level >= 6 ? 6 : level == 5 ? 5 : level == 4 ? 4 : level == 3 ? 3 : 1;
     g_rearm_after = 0;          // an explicit choice ends the probation after a time-out (and is the documented way to re-arm at once)
     q4_reset_graphs();
     if (g_stream)
@@ -623,6 +623,10 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
     const bool fp = g_fusion >= 4 && sync && ffn_pair_covers(dim, hidden_dim);
     // ... and the next layer's :300-317 with it (fusion level 5): that layer then has no QKV launch of its own
     const bool fq = fp && g_fusion >= 5 && ffn_qkv_covers(dim, hidden_dim, kv_dim, head_size, rope_table != nullptr);
+    // ... and THIS layer's :320-323 in front of it (fusion level 6): the whole layer behind its q / k / v is one launch. Only where level 3 would run the
+    // V-slice role (forms 5 / 6, bins <= 256), whose arithmetic the launch's first phase repeats
+    const int ao_form = fq ? attention_oproj_form(dim, kv_dim, head_size, p->n_heads, seq_len_bin, s->att != nullptr, att_bytes, g_att_split_min, g_att_chunk) : -1;
+    const bool fa = fq && g_fusion >= 6 && (ao_form == 5 || ao_form == 6) && layer_att_covers(dim, hidden_dim, kv_dim, p->n_heads, seq_len_bin) && !(g_skip & 15);
     bool qkv_done = false;                             // the previous launch has left q and the K / V rows of this layer
 
     for (int l = 0; l < p->n_layers; l++) {
@@ -647,7 +651,9 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
             }
             Q4_TRY(q4_rope_rotation(s->q, s->key_cache + loff, p->n_heads, p->n_kv_heads, head_size, pPos, 0, p->rope_theta));   // :317
         }
-        if (ao) {
+        if (fa) {
+            // (phases A and O of the launch below)
+        } else if (ao) {
             Q4_UNLESS(6, launch_attention_oproj(x, s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, dim, kv_dim, p->n_heads,
                                                 pPos, seq_len_bin, sync, (float*)s->att, att_bytes, g_att_split_min, g_att_chunk));
         } else {
@@ -666,8 +672,9 @@ static int run_network(const int* pPos, const Config* p, RunState* s, const Tran
                 nx = FfnQkvNext{N->rms_att_weight, &N->wq_q, &N->wq_k, &N->wq_v, s->q, s->key_cache + noff, s->value_cache + noff, pPos, rope_table,
                                 sync + SYNC_EPOCH, kv_dim, head_size};
             }
+            const FfnLayerAtt la = {s->xb, s->q, s->key_cache + loff, s->value_cache + loff, &L->wq_o, pPos, p->n_heads, kv_dim, seq_len_bin};
             Q4_UNLESS(8, launch_ffn_pair(x, s->hb, L->rms_ffn_weight, &L->wq_gate, &L->wq_up, &L->wq_down, dim, hidden_dim, sync, ffn_pair_sync_offset(dim), 0u,
-                                         with_next ? &nx : nullptr));   // :326-332 (+ the next layer's :300-317)
+                                         with_next ? &nx : nullptr, fa ? &la : nullptr));   // :326-332 (+ the next layer's :300-317, + this layer's :320-323)
             qkv_done = with_next;
             Q4_LAYER_DUMP(1);
             continue;

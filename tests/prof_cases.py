@@ -375,8 +375,8 @@ def test_ffn_pair_launch_times_out_cleanly_and_its_gather_modes_agree(q4, tmp_pa
     """The FFN half of a layer as one launch (csrc/gemv_ffn_pair.h, fusion level 4). (1) Its gather modes (profiling knob 16: first pass with sc1
     or plain loads, at once or when the wave's own down pieces have landed) are timing choices: token rings and logits identical. (2) A REAL
     time-out: the blocks of one launch do not publish (knob 17), every bounded wait runs out, the error word is set, launches queued behind it
-    do not spin again; q4_generate_ids redoes the sequence at fusion level 1 with the tokens of a clean run; q4_set_fusion(level) re-arms the launch. Levels 4 and 5 (the latter with the next
-    layer's QKV as the launch's third phase)."""
+    do not spin again; q4_generate_ids redoes the sequence at fusion level 1 with the tokens of a clean run; q4_set_fusion(level) re-arms the launch. Levels 4, 5 (with the next
+    layer's QKV as the launch's third phase) and 6 (with this layer's attention and output projection in front: the attention units do not publish either)."""
     L = q4.lib()
     p = str(tmp_path / "ffn_pair7b.bin")
     synth.write_model(p, "ffn_pair7b", seed=11)
@@ -386,14 +386,14 @@ def test_ffn_pair_launch_times_out_cleanly_and_its_gather_modes_agree(q4, tmp_pa
         t = q4.Transformer(p)
         want = t.generate_ids(prompt, 40)[0].copy()
         before = L.q4_handoff_timeouts()
-        for level in (4, 5):
+        for level in (4, 5, 6):
             for mode in (3, 0, 1, 2, 19):
                 L.q4_set_fusion(level)
                 L.q4_set_gemv_early(16, mode)
                 assert np.array_equal(t.generate_ids(prompt, 40)[0], want), (level, mode)      # bit-identical launches: the same greedy ring
                 assert L.q4_handoff_timeouts() == before and L.q4_get_fusion() == level
         L.q4_set_gemv_early(16, 3)
-        for k, level in enumerate((4, 5)):
+        for k, level in enumerate((4, 5, 6)):
             L.q4_set_fusion(level)
             L.q4_set_gemv_early(17, 1)                                  # the next FFN pair launch is captured mute
             got = t.generate_ids(prompt, 40)[0]

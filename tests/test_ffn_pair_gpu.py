@@ -1,7 +1,8 @@
 """The FFN half of a layer as ONE launch (csrc/gemv_ffn_pair.h, fusion level 4; llama2_q4.cu:326-332): rmsnorm + gate/up + SiLU, the hb vector
 handed from every CU to every CU inside the launch, the down projection on weights that are already in LDS, residual add -- and, at fusion level 5,
-the NEXT layer's rmsnorm + q/k/v + RoPE + KV write (llama2_q4.cu:300-317) as the launch's third phase. Same arithmetic in the same order as the
-launches of levels 1 / 3, so everything the network leaves behind must agree BIT FOR BIT."""
+the NEXT layer's rmsnorm + q/k/v + RoPE + KV write (llama2_q4.cu:300-317) as the launch's third phase; at the opt-in level 6 THIS layer's attention and
+output projection (llama2_q4.cu:320-323) in front of it. Same arithmetic in the same order as the launches of levels 1 / 3, so everything the network
+leaves behind must agree BIT FOR BIT."""
 import numpy as np
 import pytest
 
@@ -55,6 +56,8 @@ def test_level_4_reproduces_the_launch_sequence_bits(q4, models, name, steps, gr
         assert L.q4_get_fusion() == 4 and L.q4_handoff_timeouts() == before
         c = _run(q4, models[name], 5, graphs, steps, prompt)
         assert L.q4_get_fusion() == 5 and L.q4_handoff_timeouts() == before
+        d = _run(q4, models[name], 6, graphs, steps, prompt)
+        assert L.q4_get_fusion() == 6 and L.q4_handoff_timeouts() == before
     finally:
         L.q4_set_fusion(q4.DEFAULT_FUSION)
         L.q4_set_use_graphs(1)
@@ -66,6 +69,11 @@ def test_level_4_reproduces_the_launch_sequence_bits(q4, models, name, steps, gr
     assert a[2] == c[2], "greedy token rings differ (level 5)"
     assert np.array_equal(a[0], c[0]), "logits differ at positions %s (level 5)" % np.unique(np.argwhere(a[0] != c[0])[:, 0])[:8]
     assert np.array_equal(a[1], c[1]), "K / V rows differ at positions %s (level 5)" % np.unique(np.argwhere(a[1] != c[1])[:, 0])[:8]
+    # level 6 (opt-in): the whole layer behind its q / k / v as one launch -- layer 0's with layer 1's QKV as its last phase, layer 1's without; the attention
+    # role on sixteen waves with the P.V pass on eight, the output projection on the other half of the blocks: the same bits again, in bins 128 and 256
+    assert a[2] == d[2], "greedy token rings differ (level 6)"
+    assert np.array_equal(a[0], d[0]), "logits differ at positions %s (level 6)" % np.unique(np.argwhere(a[0] != d[0])[:, 0])[:8]
+    assert np.array_equal(a[1], d[1]), "K / V rows differ at positions %s (level 6)" % np.unique(np.argwhere(a[1] != d[1])[:, 0])[:8]
 
 
 def test_level_4_against_the_restatement(q4, orc, models):

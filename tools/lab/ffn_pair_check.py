@@ -20,7 +20,7 @@ t = api.Transformer(path)
 L.q4_set_gemv_early(16, pre % 1000); L.q4_set_gemv_early(18, pre // 1000)
 prompt = [1, 2436, 385, 3686, 388, 1048, 22796, 118]
 out = {}
-LEVELS = (3, 4, 5)
+LEVELS = tuple(int(v) for v in os.environ.get("LEVELS", "3,4,5,6").split(","))
 for lvl in LEVELS:
     L.q4_set_fusion(lvl)
     for graphs in (0, 1):
@@ -49,7 +49,7 @@ for lv in LEVELS[1:]:
   same = np.array_equal(out[(3, "ring")], out[(lv, "ring")])
   ok &= same
   print("token rings equal (level %d): %s" % (lv, same), flush=True)
-print("finite logits:", bool(np.isfinite(out[(4, 1)][0].view(np.float16).astype(np.float32)).all()))
+print("finite logits:", bool(np.isfinite(out[(LEVELS[-1], 1)][0].view(np.float16).astype(np.float32)).all()))
 
 # speed, interleaved
 for pre in pres:
@@ -66,7 +66,7 @@ for pre in pres:
   print("time-outs:", L.q4_handoff_timeouts(), "fusion:", L.q4_get_fusion())
 
 # timeline of one launch (eager, profiling build): the stamps of the last layer's launch
-L.q4_set_fusion(int(os.environ.get("TIMELINE_LEVEL", "5")))
+L.q4_set_fusion(int(os.environ.get("TIMELINE_LEVEL", str(LEVELS[-1]))))
 L.q4_set_use_graphs(0)
 nb = 256
 dbg = api.DevBuf(nbytes=4 << 20)
@@ -95,7 +95,15 @@ for trial, pre in enumerate(pres):
         print("%-46s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us" % ((name,) + tuple(np.percentile(v, [0, 10, 50, 90, 100]))))
 
     print("--- timeline, pre %d (last layer's launch; %d blocks)" % (pre, nb))
-    row("wave 0 entry", st[:, 0]); row("x landed", st[:, 1]); row("sum of squares exchanged", st[:, 2]); row("x staged", st[:, 3])
+    row("wave 0 entry", st[:, 0])
+    if (s2[128:, 41] > 0).all():      # the whole-layer launch (fusion level 6): blocks [0, 128) attention units, [128, 256) the output projection
+        na = 128
+        row("attention role done (blocks with a unit)", s2[:na, 40]); row("o-proj blocks: requests out", s2[na:, 40])
+        row("o-proj blocks: attention output gathered, staged", s2[na:, 41]); row("o-proj blocks: x published (wave 0)", s2[na:, 42])
+        row("x gathered (wave 1)", s2[:, 43]); row("   ... blocks with a unit", s2[:na, 43]); row("   ... o-proj blocks", s2[na:, 43])
+        row("x staged: blocks with a unit", st[:na, 3]); row("x staged: o-proj blocks", st[na:, 3])
+        row("gate/up done (last wave): blocks with a unit", st[:na, 32:48].max(axis=1)); row("gate/up done (last wave): o-proj blocks", st[na:, 32:48].max(axis=1))
+    row("x landed", st[:, 1]); row("sum of squares exchanged", st[:, 2]); row("x staged", st[:, 3])
     row("gate/up done, per wave", st[:, 32:48]); row("gate/up done, block's last wave", st[:, 32:48].max(axis=1))
     row("barrier A passed (wave 0)", st[:, 4]); row("published (stores issued)", st[:, 5])
     row("wave 1: first gather pass issued", st[:, 8]); row("wave 1: first gather pass back", st[:, 6]); row("wave 1: gathered", st[:, 7])
