@@ -49,6 +49,9 @@ bool ffn_pair_covers(int dim, int hidden) {
 
 // 146 KiB of LDS: the opt-in is not a stream operation -- build_transformer makes it for the model, outside any capture
 int ffn_pair_prepare() {
+    static int prepared_device = -1;       // (called in front of every launch: one hipGetDevice and a comparison once the device's opt-ins are made)
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev == prepared_device) return Q4_OK;
     int rc = lds_opt_in((const void*)ffn_pair_kernel<true, false>, FfnPairLds::BYTES);
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true>, FfnPairLds::BYTES);
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, false, true, 1>, FfnPairLds::BYTES);
@@ -61,6 +64,7 @@ int ffn_pair_prepare() {
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true, 1>, FfnPairLds::BYTES);
     if (!rc) rc = lds_opt_in((const void*)ffn_pair_kernel<true, true, true, 2>, FfnPairLds::BYTES);
 #endif
+    if (!rc) prepared_device = dev;
     return rc;
 }
 

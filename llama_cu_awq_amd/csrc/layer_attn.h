@@ -111,6 +111,8 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
                 ho.hold_until = t_entry + (((unsigned long long)size * a.hold_q16) >> 16);
             }
         }
+        // (Below the split-context bins the role requests at entry. Held back by a fixed 0.3 / 0.6 / 1.0 / 1.5 / 2.0 us behind the heads' K / V requests, round 6:
+        //  1022.3 / 1022.2 / 1022.2 / 1015.8 / 1004.6 against 1021.4 tokens/s -- level, then worse. EXPERIMENTS.md #45)
         ho.sub = g_att;
         ho.sentinel = (int)((j % a.nheads) * (a.att.head_size / 2) + a.att.head_size / 2 - 1);   // last granule of head j % heads
         gemv_q4_body<MODE_PLAIN, SLOTS, la_ocols(SLOTS), false, 5, 1, HALF, ROLE_CONSUMER>(a.oproj, j, 0, ho);

@@ -126,6 +126,8 @@ struct LabHooks {
 extern LabHooks g_lab;      // gemv_ffn_strip.hip
 static inline size_t ffn_pair_sync_offset(int dim) { return (attention_sync_words(dim) + 1) & ~(size_t)1; }   // 8-byte aligned (granules), behind the attention words
 int classifier_with_final_norm(q4_half* logits, q4_half* x, const q4_half* rms_w, const q4_half* wcls, int dim, int vocab);   // q4_kernels.hip
+// (One host thread drives the library, like the reference's: the opt-in map, the prepared-device words of the *_prepare functions, the graph sets and the
+// stream caches are plain statics.)
 // Opt `kernel` in to `bytes` of dynamic LDS (more than 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize), once per (kernel, device):
 // a process-wide flag would leave a second device's kernels at 64 KiB after q4_set_device. Not a stream operation: outside any capture.
 int lds_opt_in(const void* kernel, size_t bytes);

@@ -497,11 +497,16 @@ int launch_argmax_feed(const q4_half* x, int size, int* result, volatile int* pP
 namespace q4 {
 // the LDS opt-in is not a stream operation: q4_set_device and build_transformer make it (q4_runtime.hip), outside any capture
 int cls_strip_prepare() {
+    // called in front of every launch of the kernel: one hipGetDevice and a comparison once the device's opt-ins are made (single host thread: q4_internal.h)
+    static int prepared_device = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev == prepared_device) return Q4_OK;
     int rc = Q4_OK;     // (once per device: lds_opt_in)
     if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<8, true, CLS_D>, StripClsLds<8, CLS_D>::BYTES);
     if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<8, false, CLS_D>, StripClsLds<8, CLS_D>::BYTES);
     if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<10, true, CLS_D>, StripClsLds<10, CLS_D>::BYTES);
     if (!rc) rc = lds_opt_in((const void*)cls_strip_kernel<10, false, CLS_D>, StripClsLds<10, CLS_D>::BYTES);
+    if (!rc) prepared_device = dev;
     return rc;
 }
 // (the greedy sampler as this launch's epilogue was built and measured level in round 4: EXPERIMENTS.md #19)

@@ -26,18 +26,41 @@ def aggregate(elapsed_s, tokens, dist=None, device="cpu"):
 
 
 def free_port():
+    """A port nobody listens on right now. (The socket is closed before the children bind -- torch's rendezvous needs to bind it itself --, so another
+    process can take the port in between; spawn() then fails loudly in the rendezvous of rank 0 and can simply be run again.)"""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 
 
-def spawn(n, argv, env=None, timeout=None):
+def _stop(procs, live, grace):
+    """terminate() the live replicas, give them `grace` seconds, kill() what is left, and reap every one of them (no zombies)."""
+    import time
+    for o in live:
+        if procs[o].poll() is None:
+            procs[o].terminate()
+    t_end = time.time() + grace
+    while time.time() < t_end and any(procs[o].poll() is None for o in live):
+        time.sleep(0.05)
+    for o in live:
+        if procs[o].poll() is None:      # stuck in a HIP / RCCL call that ignores SIGTERM
+            procs[o].kill()
+    for o in live:
+        try:
+            procs[o].wait(timeout=10)
+        except Exception:
+            pass
+
+
+def spawn(n, argv, env=None, timeout=1800, grace=10.0):
     """Launch `n` replica processes of the command `argv` (one per GPU of this node) with the torch.distributed environment a
     launcher would give them -- RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port -- and wait for all
     of them. HIP_VISIBLE_DEVICES is left alone: every replica selects its own GPU by LOCAL_RANK (q4_set_device), so a box with fewer
     than `n` GPUs fails loudly there. Rank 0's stdout is this process's stdout (the one JSON line of bench.py); the other ranks'
-    stdout goes to stderr. Returns the largest exit code; a replica that fails ends the others."""
+    stdout goes to stderr. Returns the largest exit code. A replica that fails ends the others (they would wait in the barrier for
+    ever): SIGTERM, `grace` seconds, SIGKILL, and every process is reaped. After `timeout` seconds (None: never) the same happens
+    and the result is 124."""
     import os
     import subprocess
     import sys
@@ -54,6 +77,7 @@ def spawn(n, argv, env=None, timeout=None):
     rc = 0
     live = set(range(n))
     while live:
+        failed = False
         for r in sorted(live):
             c = procs[r].poll()
             if c is None:
@@ -61,11 +85,12 @@ def spawn(n, argv, env=None, timeout=None):
             live.discard(r)
             if c != 0:
                 rc = max(rc, c if c > 0 else 1)
-                for o in live:          # a failed replica would leave the others in the barrier for ever
-                    procs[o].terminate()
+                failed = True
+        if failed and live:
+            _stop(procs, live, grace)
+            return rc
         if timeout is not None and time.time() - t0 > timeout:
-            for o in live:
-                procs[o].kill()
+            _stop(procs, live, grace)
             return max(rc, 124)
         time.sleep(0.05)
     return rc

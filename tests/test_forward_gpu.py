@@ -131,8 +131,15 @@ def test_in_launch_handoffs_reproduce_the_launch_sequence_bits(q4, models, obser
             # a single fp16 value of the residual stream rounding the other way (one ulp of a unit-scale value = 9.8e-4 .. 2e-3) moves every
             # logit by up to that much: bounded in units of a unit-scale ulp, not of the logit's own (a logit of 1e-5 would read as 1000 ulps)
             af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
-            err = float((np.abs(af - bf) / np.maximum(1.0, np.abs(bf))).max())
-            assert err <= 4e-3 and (af != bf).mean() <= 0.6, (pos, err, float((af != bf).mean()))
+            big = np.abs(bf) >= 1.0
+            # logits of unit scale and above: in ulps of the logit itself (the old exact check's successor must still see a regression there);
+            # below: absolute. Bounds = twice the measured maxima (1 ulp, 9.8e-4: profiles/r06_parity_observed.json, "fusion0_vs_1_head128_k5120")
+            ulp = np.spacing(np.abs(bf).astype(np.float16)).astype(np.float64)
+            ulps_big = float((np.abs(af - bf)[big] / ulp[big]).max()) if big.any() else 0.0
+            abs_small = float(np.abs(af - bf)[~big].max()) if (~big).any() else 0.0
+            observed.setdefault("fusion0_vs_1_head128_k5120", {})[str(pos)] = {"max_ulps_of_logits_above_1": ulps_big, "max_abs_below_1": abs_small,
+                                                                                "share_of_logits_that_differ": float((af != bf).mean())}
+            assert ulps_big <= 2.0 and abs_small <= 2e-3 and (af != bf).mean() <= 0.6, (pos, ulps_big, abs_small, float((af != bf).mean()))
             break                                       # later positions follow their own greedy tokens
         assert np.array_equal(a, b), "logits differ at position %d (fusion 0 vs 1)" % pos
     if name != "head128_k5120":

@@ -95,6 +95,41 @@ def test_a_failing_replica_fails_the_job(tmp_path):
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+_STUCK = """
+import os, signal, sys, time
+rank = int(os.environ["RANK"])
+if rank == 0:
+    time.sleep(0.5)
+    sys.exit(5)
+signal.signal(signal.SIGTERM, signal.SIG_IGN)     # a peer inside a HIP / RCCL call that does not return
+open(sys.argv[1], "w").write(str(os.getpid()))
+time.sleep(600)
+"""
+
+
+def test_a_peer_that_ignores_sigterm_is_killed_and_reaped(tmp_path):
+    """After a replica has failed, the others get SIGTERM, a grace period, SIGKILL, and are waited for: the launcher returns the failure's
+    exit code within seconds and leaves no process behind."""
+    import subprocess
+    import time
+    script = tmp_path / "stuck.py"
+    script.write_text(_STUCK)
+    pidfile = tmp_path / "pid"
+    drv = ("import sys; sys.path.insert(0, %r); from llama_cu_awq_amd import replicas; "
+           "sys.exit(replicas.spawn(2, [sys.executable, %r, %r], timeout=120, grace=1.0))" % (ROOT, str(script), str(pidfile)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 5 and time.time() - t0 < 30
+    pid = int(pidfile.read_text())
+    gone = False
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        gone = True
+    assert gone, "the stuck replica is still there"
+
+
 def test_bench_gpus_flag_spawns_replicas():
     """bench.py reads --gpus: without WORLD_SIZE and N > 1 it goes through replicas.spawn before anything touches a GPU."""
     src = open(os.path.join(ROOT, "bench.py")).read()

@@ -1,5 +1,5 @@
 // Does a dispatch without the AQL barrier bit (hipExtAnyOrderLaunch) overlap its predecessor on gfx950, and what does
-// two-stream concurrency look like?  hipcc --offload-arch=gfx950 -O2 tools/lab/anyorder.hip -o tools/anyorder
+// two-stream concurrency look like?  hipcc --offload-arch=gfx950 -O2 tools/lab/anyorder.hip -o tools/lab/anyorder
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // nibble pairs as in the dequant-free GEMV body, b = fp16 activations, c = a running fp32 sum -- the device result is held against the exact
 // sum (double: the two products are exact, the three-term sum is exact in double here) rounded to fp32 three ways: to nearest even, toward
 // zero, toward minus infinity. Round 5 (tools/bias_probe.py) found a signed error of the GEMVs that the restatement does not have; this
-// names its source.      hipcc --offload-arch=gfx950 -O2 tools/lab/t_dot2_round.hip -o tools/t_dot2_round && tools/t_dot2_round
+// names its source.      hipcc --offload-arch=gfx950 -O2 tools/lab/t_dot2_round.hip -o tools/lab/t_dot2_round && tools/lab/t_dot2_round
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

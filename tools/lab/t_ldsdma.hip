@@ -1,7 +1,7 @@
 // t_ldsdma.hip -- where does `buffer_load_dwordx4 ... lds` put its bytes on gfx950? (tools/, not product)
 // Probes, each on a poisoned 160 KiB LDS: M0 below and above 64 KiB, the instruction's immediate offset (does it move the
 // LDS address as well as the global one?), the 4-byte form, and vmcnt accounting. Prints where the data landed.
-//   hipcc --offload-arch=gfx950 -O2 -o tools/t_ldsdma tools/lab/t_ldsdma.hip && tools/t_ldsdma
+//   hipcc --offload-arch=gfx950 -O2 -o tools/lab/t_ldsdma tools/lab/t_ldsdma.hip && tools/lab/t_ldsdma
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

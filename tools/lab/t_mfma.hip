@@ -1,6 +1,6 @@
 // v_mfma_f32_4x4x4_16b_f16 as a per-lane dot4 for the int4 GEMV: (1) are fp16 DENORMAL A inputs multiplied exactly?
 // (2) issue cost next to the nibble-extraction VALU ops, against the v_dot2c form.
-// hipcc --offload-arch=gfx950 -O2 tools/lab/t_mfma.hip -o tools/t_mfma
+// hipcc --offload-arch=gfx950 -O2 tools/lab/t_mfma.hip -o tools/lab/t_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

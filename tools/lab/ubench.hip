@@ -1,5 +1,5 @@
 // ubench.hip -- VALU issue-rate / dependent-latency microbenchmarks for the instructions the int4 GEMV leans on.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/lab/ubench.hip -o tools/ubench ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/lab/ubench.hip -o tools/lab/ubench ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
