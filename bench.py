@@ -248,7 +248,7 @@ def main():
             if os.path.exists(cpath):
                 import csv
                 for r in csv.DictReader(open(cpath)):
-                    if (("ffn_pair_kernel<true, false, true>" in r["kernel"]) if three else ("ffn_pair_kernel<" in r["kernel"])) if pair else ("gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]):   # the dominant launch: the FFN pair (csrc/gemv_ffn_pair.h), else the fused gate/up launch (csrc/gemv_strip.h)
+                    if (("ffn_pair_kernel<true, false, true" in r["kernel"]) if three else ("ffn_pair_kernel<" in r["kernel"])) if pair else ("gemv_q4_kernel<2," in r["kernel"] or "ffn_strip_kernel<" in r["kernel"] or "ffn_strip_pair_kernel<" in r["kernel"]):   # the dominant launch: the FFN pair (csrc/gemv_ffn_pair.h), else the fused gate/up launch (csrc/gemv_strip.h)
                         rocprof_us, rocprof_src = float(r["avg_us"]), "profiles/" + os.path.basename(cpath)
                         break
             if rocprof_us is not None:
@@ -301,7 +301,7 @@ def main():
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
                             "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
-                            kb[dom_id][0]: ("ffn_pair_kernel<true, false, true>",) if three else ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
+                            kb[dom_id][0]: ("ffn_pair_kernel<true, false, true",) if three else ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
                 if three:
                     prefixes.pop("qkv_rmsnorm_rope_q4", None)
                 for nm_, pre_ in prefixes.items():

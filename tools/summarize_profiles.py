@@ -65,7 +65,7 @@ def algorithmic(kernel, model, ntok):
         return 2 * qweight_bytes(d, h) + 2 * d * 2 + h * 2
     if kernel.startswith("ffn_pair_kernel"):     # fusion level 4: gate/up + down in one launch (bench.py kernel_bytes id 10); the hb hand-off inside the launch is not algorithmic
         pair = 2 * qweight_bytes(d, h) + qweight_bytes(h, d) + 4 * d * 2 + h * 2
-        if re.match(r"ffn_pair_kernel<\w+, \w+, true>", kernel):   # fusion level 5: + the next layer's rmsnorm + q/k/v + RoPE + KV write (id 11)
+        if re.match(r"ffn_pair_kernel<\w+, \w+, true[,>]", kernel):   # fusion level 5: + the next layer's rmsnorm + q/k/v + RoPE + KV write (id 11)
             return pair + 3 * qweight_bytes(d, d) + d * 2 + 3 * d * 2
         return pair
     if kernel.startswith("gemv_q4_kernel<1"):
@@ -124,8 +124,8 @@ if "7b_n256" in traffic:     # bench.py reads the dominant kernel's figure from 
         if k.replace("q4::", "").startswith(("gemv_q4_kernel<2", "ffn_engine_kernel", "ffn_strip_kernel", "ffn_strip_pair_kernel")) and "0" not in traffic:   # the fused gate/up launch in whatever form the product runs it
             traffic["0"] = {"kernel": "ffn_rmsnorm_gate_up_silu_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
-        three_phase = any(kk.replace("q4::", "").startswith("ffn_pair_kernel<true, false, true>") for kk in traffic["7b_n256"])
-        if k.replace("q4::", "").startswith("ffn_pair_kernel<true, false, true>" if three_phase else "ffn_pair_kernel"):      # ... or, at fusion levels 4 / 5, the FFN launch: the decode path's dominant launch
+        three_phase = any(kk.replace("q4::", "").startswith("ffn_pair_kernel<true, false, true") for kk in traffic["7b_n256"])
+        if k.replace("q4::", "").startswith("ffn_pair_kernel<true, false, true" if three_phase else "ffn_pair_kernel"):      # ... or, at fusion levels 4 / 5, the FFN launch: the decode path's dominant launch
             traffic["0"] = {"kernel": "ffn_gate_up_down_accum_then_next_qkv_rope_q4" if three_phase else "ffn_rmsnorm_gate_up_silu_down_accum_q4", "traffic_bytes_per_launch": e["traffic_bytes_per_launch"],
                             "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
 traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh) over eager greedy decodes of the "
