@@ -250,12 +250,12 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const bool gathA = tid < nchA;
         unsigned deadA = 0u;
         auto gather_vec = [&](const u32x2v* gran, u32x4& out, u32x4& other) {      // other: an asm load of the caller that lands under the pass
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(nchA * 32u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(gran_area_words(nchA * 4u) * 4u), 0x00020000);
             bool need = true, failed = false;
             unsigned tries = 0;
             for (;;) {
                 u32x4 g0, g1;
-                const unsigned o0 = need ? tid * 32u : 0x7FFFFF00u;
+                const unsigned o0 = need ? gran_slot(4u * tid) * 8u : 0x7FFFFF00u;
                 // (sc1: past the L1; see the third phase's gather)
                 asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1" : "=&v"(g0), "=&v"(g1) : "v"(o0), "s"(rg) : "memory");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             if (tid == 0 && deadA == 0u) {
                 const unsigned sentinel = (jb % la.nheads) * ((unsigned)la.att.head_size >> 1) + ((unsigned)la.att.head_size >> 1) - 1u;
                 unsigned i = 0;
-                while (load_granule(la.agran, sentinel)[1] != tagA && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
+                while (load_granule(la.agran, gran_slot(sentinel))[1] != tagA && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
                 if (i >= POLL_LIMIT) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             block_barrier_lds();
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
                     xo = f2h(r);                                // :231 -- as granules only: RunState::x is written once per launch, by the block that owns the
                 }                                               // column in phase 2 (two CUs' plain stores to one line may be written back in either order)
                 const unsigned partner = (unsigned)__shfl_down((int)xo, 1);
-                if ((lane & 1u) == 0u && lane < 32u) store_granule(la.xogran + ((32u * jb + lane) >> 1), (unsigned)xo | (partner << 16), tagA);
+                if ((lane & 1u) == 0u && lane < 32u) store_granule(la.xogran + gran_slot((32u * jb + lane) >> 1), (unsigned)xo | (partner << 16), tagA);
                 FPSTAMP2(42);
             }
             if (wave < NSTAGE) issue_ahead_of(wave);
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         }
         if (QKV && wave == 0) {                         // the block's slice of the new residual stream, for every other block: column pairs (c0d and nc2 are even)
             const unsigned partner = (unsigned)__shfl_down((int)xnew, 1);
-            if ((lane & 1u) == 0u && (int)lane < nc2) store_granule(q3.xgran + ((c0d + lane) >> 1), (unsigned)xnew | (partner << 16), tag);
+            if ((lane & 1u) == 0u && (int)lane < nc2) store_granule(q3.xgran + gran_slot((c0d + lane) >> 1), (unsigned)xnew | (partner << 16), tag);
         }
     }
     if (QKV) {
@@ -764,13 +764,14 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         if (gath) {
             const u32x4* pw = reinterpret_cast<const u32x4*>(q3.rms_w) + tid;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wr3) : "v"(pw) : "memory");
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)q3.xgran, 0, (int)(nch3 * 32u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)q3.xgran, 0, (int)(gran_area_words(nch3 * 4u) * 4u), 0x00020000);
+            const unsigned xoff3 = gran_slot(4u * tid) * 8u;      // chunk tid = granules 4 tid .. 4 tid + 3, inside one record
             bool need = true;
             unsigned tries = 0, passes = 0;
             bool failed = false;
             for (;;) {
                 u32x4 g0, g1;
-                const unsigned o0 = need ? tid * 32u : 0x7FFFFF00u;
+                const unsigned o0 = need ? xoff3 : 0x7FFFFF00u;
                 // sc1 from the first pass on: the blocks reach this seam up to a microsecond apart, an early plain read would leave stale lines in this CU's L1 (the
                 // XCDs' L2s are kept coherent, tools/lab/t_l2stale.hip). Plain loads with the L1 invalidated in front of every retry were measured: `buffer_inv sc1`
                 // takes ~10 us a pass (1019 -> 728 tokens/s), `buffer_inv sc0` does not invalidate the L1 at all (the waits run out)

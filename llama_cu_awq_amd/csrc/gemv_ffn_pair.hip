@@ -17,7 +17,7 @@ static void fill_gate_up(GemvArgs& a, int dim, int hidden) {
 // words the launch needs behind the model's other hand-off words: hidden / 2 granules of 8 bytes for hb, then dim / 2 for the residual stream
 // between its second and third phase (fusion level 5)
 // between its second and third phase (fusion level 5), then dim / 2 for the residual stream between the output projection and the FFN half (level 6)
-size_t ffn_pair_sync_words(int dim, int hidden) { return (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 4; }
+size_t ffn_pair_sync_words(int dim, int hidden) { return (size_t)(hidden / 2) * 2 + 2 * gran_area_words((size_t)dim / 2); }   // hb dense; the two x vectors spread (gemv_q4.h, gran_slot)
 
 // fusion level 6: the launch begins with the layer's attention and output projection. Llama-2-7B's shape below the split-context bins: 128-wide heads (four
 // 64-byte V slices each), as many (head, slice) units as half the blocks -- the other half are the output projection, 32 columns of two k-slots each; the attention's arithmetic is
@@ -105,7 +105,7 @@ int launch_ffn_pair(q4_half* x, q4_half* hb, const q4_half* rms_w, const QWeight
         la.att = {att->xb, att->q, att->kc, att->vc, head_size, dim / att->kv_dim, att->kv_dim, att->pPos, (float)(1.0 / sqrt((double)head_size)), att->seq_len_bin, nullptr};
         fill_mat(la.o, att->wo);
         la.agran = reinterpret_cast<u32x2v*>(sync + SYNC_GRANULES);
-        la.xogran = reinterpret_cast<u32x2v*>(sync + gran_word + (size_t)(hidden / 2) * 2 + (size_t)(dim / 2) * 2);
+        la.xogran = reinterpret_cast<u32x2v*>(sync + gran_word + (size_t)(hidden / 2) * 2 + gran_area_words((size_t)dim / 2));
         la.nheads = (unsigned)att->n_heads; la.natt = 4u * (unsigned)att->n_heads;
     }
     const unsigned pairs = (unsigned)hidden / 2u;
