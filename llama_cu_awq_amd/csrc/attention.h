@@ -296,7 +296,7 @@ __device__ __forceinline__ void attention_body(const AttArgs& a, const int h, co
 #ifdef Q4_PROFILING
             if (!ho.mute)
 #endif
-            store_granule(ho.pub + (size_t)h * (head_size / 2) + g, as_u(hh), ho.tag);
+            store_granule(ho.pub + line_slot((unsigned)(h * (head_size / 2) + g)), as_u(hh), ho.tag);
             *reinterpret_cast<unsigned*>(a.output + (size_t)h * head_size + g * 2) = as_u(hh);
         }
         if (STAMPS && a.dbg && lane == 0 && vs == 0) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void attention_split_body(const SplitArgs& a, const i
 #ifdef Q4_PROFILING
         if (!ho.mute)
 #endif
-        store_granule(ho.pub + (size_t)h * (head_size / 2) + tid, data, ho.tag);
+        store_granule(ho.pub + line_slot((unsigned)(h * (head_size / 2)) + tid), data, ho.tag);
 #ifdef Q4_PROFILING
         SPLIT_STAMP(7);
         dump();

@@ -249,13 +249,13 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         const unsigned nchA = (unsigned)a.K >> 3;                          // 512 chunks of eight halves: one per thread of waves 0 .. 7
         const bool gathA = tid < nchA;
         unsigned deadA = 0u;
-        auto gather_vec = [&](const u32x2v* gran, u32x4& out, u32x4& other, const bool spread) {      // other: an asm load of the caller that lands under the pass
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(gran_area_words(nchA * 4u) * 4u), 0x00020000);
+        auto gather_vec = [&](const u32x2v* gran, u32x4& out, u32x4& other, const bool lines) {      // other: an asm load of the caller that lands under the pass
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)((lines ? line_area_words(nchA * 4u) : gran_area_words(nchA * 4u)) * 4u), 0x00020000);
             bool need = true, failed = false;
             unsigned tries = 0;
             for (;;) {
                 u32x4 g0, g1;
-                const unsigned o0 = need ? (spread ? gran_slot(4u * tid) * 8u : tid * 32u) : 0x7FFFFF00u;
+                const unsigned o0 = need ? (lines ? line_slot(4u * tid) : gran_slot(4u * tid)) * 8u : 0x7FFFFF00u;
                 // (sc1: past the L1; see the third phase's gather)
                 asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16 sc1" : "=&v"(g0), "=&v"(g1) : "v"(o0), "s"(rg) : "memory");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,13 +312,13 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
             if (tid == 0 && deadA == 0u) {
                 const unsigned sentinel = (jb % la.nheads) * ((unsigned)la.att.head_size >> 1) + ((unsigned)la.att.head_size >> 1) - 1u;
                 unsigned i = 0;
-                while (load_granule(la.agran, sentinel)[1] != tagA && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
+                while (load_granule(la.agran, line_slot(sentinel))[1] != tagA && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
                 if (i >= POLL_LIMIT) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             block_barrier_lds();
             if (gathA) {
                 u32x4 av = {0u, 0u, 0u, 0u};
-                gather_vec(la.agran, av, wraw, false);      // (the attention output: dense)
+                gather_vec(la.agran, av, wraw, true);       // (the attention output: whole lines, line_slot)
                 // stage: gemv_q4_body's layout for a vector that is multiplied as it is (odd units negated)
                 const unsigned sgn = q4_stage_sign_bits(tid);
                 const u32x4 pv = permute_x8(q4_signed_x(av, sgn));
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
         if (gathA) {
             const u32x4* pw = arg_rms + tid;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wraw) : "v"(pw) : "memory");
-            gather_vec(la.xogran, xraw, wraw, true);        // (the residual stream: spread, gran_slot)
+            gather_vec(la.xogran, xraw, wraw, false);       // (the residual stream: half-line records, gran_slot)
             // the residual of the block's sixteen down columns (chunks 2 b and 2 b + 1): kept in LDS until phase 2 ends
             if ((tid >> 1) == blockIdx.x) *reinterpret_cast<u32x4*>(smem + P::TOT2 + 128u + (tid & 1u) * 16u) = xraw;
         }

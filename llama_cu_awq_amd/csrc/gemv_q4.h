@@ -101,11 +101,14 @@ constexpr unsigned POLL_LIMIT = 1u << 20;   // ~0.25 us per poll: give up after 
 // granules (64 bytes -- what one block publishes with one store instruction), one record every GRAN_STRIDE granules (2 KiB). Dense, a 4096-wide vector is 128
 // lines of 16 KB that all 256 CUs read at once -- two blocks on different XCDs write into each line, a handful of memory channels serve 32 K requests a pass.
 // Spread over 512 KB: record every 64 / 128 / 256 / 512 / 1024 / 2048 / 4096 B: 1021.0 / 1019.2 / 1027.8 / 1024.6 / 1025.9 / 1030.3 / 1026.1 tokens/s.
-// The ATTENTION OUTPUT stays dense: a (head, V slice) unit publishes one whole 128-byte line with one store; spread, it measured -0.3 % (-n 256), -0.5 %
-// (-n 2048) (EXPERIMENTS.md #48).
+// (The attention output in such half-line records measured -0.3 % / -0.5 %: its units publish whole lines -- line_slot below. EXPERIMENTS.md #48)
 constexpr unsigned GRAN_REC = 8u, GRAN_STRIDE = 256u;
 __host__ __device__ constexpr unsigned gran_slot(unsigned g) { return (g / GRAN_REC) * GRAN_STRIDE + (g % GRAN_REC); }
 __host__ __device__ constexpr size_t gran_area_words(size_t granules) { return (granules + GRAN_REC - 1) / GRAN_REC * GRAN_STRIDE * 2; }   // 32-bit words of a spread vector
+// The attention output: whole 128-byte lines (16 granules: what a (head, V slice) unit publishes with one store) one per 2 KiB: +0.2 % (-n 256), +0.1 % (-n 2048).
+// (The hb vector as lines one per 2 KiB measured level: it stays dense -- its first gather pass goes through the XCDs' L2s.)
+__host__ __device__ constexpr unsigned line_slot(unsigned g) { return (g >> 4) * GRAN_STRIDE + (g & 15u); }
+__host__ __device__ constexpr size_t line_area_words(size_t granules) { return (granules + 15) / 16 * GRAN_STRIDE * 2; }
 __device__ __forceinline__ void store_granule(u32x2v* p, unsigned data, unsigned tag) {
     const u32x2v g = {data, tag};
     asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(g) : "memory");
@@ -293,7 +296,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
             const unsigned u = tid + i * blockDim.x;
             const unsigned uc = u < nchunks ? u : nchunks - 1;
             for (unsigned tries = 0;; tries++) {
-                const u32x4 g01 = load_granule2(ho.sub, uc * 4), g23 = load_granule2(ho.sub, uc * 4 + 2);
+                const u32x4 g01 = load_granule2(ho.sub, line_slot(uc * 4)), g23 = load_granule2(ho.sub, line_slot(uc * 4 + 2));
                 xraw[i] = (u32x4){g01[0], g01[2], g23[0], g23[2]};
                 if (g01[1] == ho.tag && g01[3] == ho.tag && g23[1] == ho.tag && g23[3] == ho.tag) break;
                 if (tries >= POLL_LIMIT / 4 || ho.dead != 0u) { ok = false; break; }
@@ -424,7 +427,7 @@ __device__ __forceinline__ void gemv_q4_body(const GemvArgs& a, const unsigned v
         static_assert(ROLE != ROLE_CONSUMER || ABL == 5, "consumer role: all loads first");
         if (tid == 0 && ho.dead == 0u) {   // one lane polls ONE granule (spread over lines: few pollers per line) ...
             unsigned i = 0;
-            while (load_granule(ho.sub, (unsigned)ho.sentinel)[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
+            while (load_granule(ho.sub, line_slot((unsigned)ho.sentinel))[1] != ho.tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
             if (i >= POLL_LIMIT) __hip_atomic_store(ho.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();

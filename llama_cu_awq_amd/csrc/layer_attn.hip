@@ -159,6 +159,6 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
 }
 
 // words of hand-off state a model needs: the error / epoch / arrival-counter page, then dim/2 granules of 8 bytes
-size_t attention_sync_words(int dim) { return SYNC_GRANULES + (size_t)(dim / 2) * 2; }
+size_t attention_sync_words(int dim) { return SYNC_GRANULES + line_area_words((size_t)dim / 2); }   // (whole lines one per 2 KiB: gemv_q4.h, line_slot)
 
 }  // namespace q4
