@@ -122,6 +122,120 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
 #endif
 }
 
+// The same launch on SIXTEEN-wave blocks, for Llama-2-7B's shape below the split-context bins (128-wide heads, K = dim = 4096 in two k-slots): the attention
+// role's (head, V slice) units take half as many wave instructions per wave for the scores (attention_body on sixteen waves, the P.V pass on eight: the
+// eight-wave role's bits, attention.h VW) -- round 6's whole-layer experiment measured the role at 2.7-3.0 us against 3.2-4.1 on eight waves --, and the o-proj
+// role multiplies ONE column per wave (dim / 16 blocks): reduce4_q4(c, 0, 0, 0) is row 0 of the two-column form's reduction, bit for bit. Same protocol.
+// ATT 5 / 6 as above (bins 128 / 256).
+constexpr int LA16_WAVES = 16;
+constexpr size_t LA16_LDS = 16 * 1024;     // the attention role's scratch (32 + 16 x 128 + 256 floats) or the o-proj role's staged vector (8.5 KiB)
+template <int ATT>
+__global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(const AttOprojArgs a) {
+    static_assert(ATT == 5 || ATT == 6, "V-slice forms");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* const sync_words = a.sync;
+    unsigned zero_off = 0;
+    asm volatile("" : "+v"(zero_off));
+    const u32x2v ee = load_granule(reinterpret_cast<const u32x2v*>(sync_words), zero_off);     // [0] the error word, [1] the epoch (see attention_oproj_kernel)
+    u32x2v* const g_att = reinterpret_cast<u32x2v*>(sync_words + SYNC_GRANULES);
+    if (b < a.natt) {
+        Handoff ho = {};
+        ho.error = sync_words + SYNC_ERROR;
+        ho.tag = ee[1];
+        ho.dead = ee[0];
+        ho.pub = g_att;
+#ifdef Q4_PROFILING
+        ho.mute = a.mute != 0;
+#endif
+        attention_body<16, ATT == 5 ? 2 : 4, LA16_WAVES, 2, false, 4, ATT == 6 ? 128 : 0, 8>(a.att, (int)(b % a.nheads), ho, (int)(b / a.nheads));
+        return;
+    }
+    // ---- o-proj role: column n = 16 j + wave, its two k-slots requested at entry (gemv_q4.h's loads), then ONE granule polled by one lane, the vector gathered
+    // by waves 0 .. 7 (every granule validates itself), staged as gemv_q4_body stages a vector that is multiplied as it is
+    const unsigned j = b - a.natt;
+    const GemvArgs& o = a.oproj;
+    const unsigned n = 16u * j + (unsigned)wave;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].w, 0, o.N * o.pw4 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].z, 0, o.N * o.pzh * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].s, 0, o.N * o.sh * 2, 0x00020000);
+    u32x4 W[2];
+    unsigned ZW[2];
+    uint16_t SC[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const unsigned jj = 64u * (unsigned)s + lane;
+        ZW[s] = __builtin_amdgcn_raw_buffer_load_b32(rz, (jj >> 5) * 4u, n * (unsigned)o.pzh * 4u, Q4_ZS_AUX);
+        SC[s] = __builtin_amdgcn_raw_buffer_load_b16(rs, (jj >> 2) * 2u, n * (unsigned)o.sh * 2u, Q4_ZS_AUX);
+        W[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, jj * 16u, n * (unsigned)o.pw4 * 16u, Q4_W_AUX);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned tag = ee[1], dead = ee[0];
+    unsigned* const error = sync_words + SYNC_ERROR;
+    if (tid == 0 && dead == 0u) {
+        const unsigned sentinel = (j % a.nheads) * ((unsigned)a.att.head_size >> 1) + ((unsigned)a.att.head_size >> 1) - 1u;
+        unsigned i = 0;
+        while (load_granule(g_att, line_slot(sentinel))[1] != tag && ++i < POLL_LIMIT) __builtin_amdgcn_s_sleep(2);
+        if (i >= POLL_LIMIT) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                    // [2][4][64] x 16 B permuted x
+    float* sx = reinterpret_cast<float*>(smem + 2 * 4096);        // [2][64] -(sum of the 32 x) * 2^-20
+    if (tid < 512u) {                                             // one 8-half chunk per thread: K = 4096
+        u32x4 xraw = {0u, 0u, 0u, 0u};
+        bool ok = true;
+        for (unsigned tries = 0;; tries++) {
+            const u32x4 g01 = load_granule2(g_att, line_slot(tid * 4u)), g23 = load_granule2(g_att, line_slot(tid * 4u + 2u));
+            xraw = (u32x4){g01[0], g01[2], g23[0], g23[2]};
+            if (g01[1] == tag && g01[3] == tag && g23[1] == tag && g23[3] == tag) break;
+            if (tries >= POLL_LIMIT / 4 || dead != 0u) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && dead == 0u) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned sgn = q4_stage_sign_bits(tid);
+        const u32x4 pv = permute_x8(q4_signed_x(xraw, sgn));
+        const h2 ones = {(f16_t)1.0f, (f16_t)1.0f};
+        float cb = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; d4++) cb = __builtin_amdgcn_fdot2(as_h2(pv[d4]), ones, cb, false);
+        cb += dpp_mov<0xB1>(cb); cb += dpp_mov<0x4E>(cb);
+        const unsigned u = tid >> 2, d = tid & 3u;
+        xs[(((u >> 6) * 4 + d) << 6) + (u & 63u)] = pv;
+        if (d == 0) sx[u] = cb * -9.5367431640625e-07f;
+    }
+    __syncthreads();
+    float c = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        u32x4 X[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) X[d] = xs[((s * 4 + d) << 6) + lane];
+        const float corr = sx[s * 64 + lane];
+        float acc_e = 0.f, acc_o = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const unsigned ww = W[s][d], tt = ww >> 8;
+            acc_e = __builtin_amdgcn_fdot2(as_h2(ww & 0x000F000Fu), as_h2(X[d][0]), acc_e, false);
+            acc_o = __builtin_amdgcn_fdot2(as_h2(ww & 0x00F000F0u), as_h2(X[d][1]), acc_o, false);
+            acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][2]), acc_e, false);
+            acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][3]), acc_o, false);
+        }
+        const float zf = (float)((ZW[s] >> (((lane >> 2) & 7u) * 4u)) & 0xFu);
+        float t = __builtin_fmaf(acc_e, 16.f, acc_o);
+        t = __builtin_fmaf(zf, corr, t);
+        c = __builtin_fmaf(h2f(SC[s]), t, c);
+    }
+    const float tot = reduce4_q4(c, 0.f, 0.f, 0.f) * 1048576.f;
+    if (lane == 0 && (int)n < o.N) {
+        q4_half* out = o.out[0];
+        float r = tot;
+        if (o.accum) r += h2f(out[n]);                            // gpu_kernels.h:229-230
+        out[n] = f2h(r);                                          // :231
+    }
+}
+int launch_attention_oproj16(int att, dim3 grid, const AttOprojArgs& a, int* max_blocks_per_cu);   // layer_attn.hip
+
 // one translation unit per head size (layer_attn_h64.hip, layer_attn.hip, layer_attn_h256.hip)
 typedef int (*AttOprojLaunch)(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);
 int launch_attention_oproj_h64(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu);

@@ -9,6 +9,23 @@ namespace q4 {
 int launch_attention_oproj_h128(int slots_kind, int att, dim3 grid, dim3 block, size_t smem, const AttOprojArgs& a, int* max_blocks_per_cu)
     Q4_AO_DISPATCH(16)
 
+int launch_attention_oproj16(int att, dim3 grid, const AttOprojArgs& a, int* max_blocks_per_cu) {
+    auto go = [&](auto kernel) -> int {
+        if (max_blocks_per_cu) {
+            int n = 0;
+            Q4_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, LA16_WAVES * 64, LA16_LDS));
+            *max_blocks_per_cu = n;
+            return Q4_OK;
+        }
+        Q4_LAUNCH(kernel, grid, dim3(LA16_WAVES * 64), LA16_LDS, a);
+        Q4_LAUNCH_CHECK();
+        return Q4_OK;
+    };
+    if (att == 5) return go(attention_oproj16_kernel<5>);
+    if (att == 6) return go(attention_oproj16_kernel<6>);
+    return Q4_ERR_UNSUPPORTED_SIZE;
+}
+
 static void fill_mat(GemvMat& m, const QWeight* w) { m.w = w->weight; m.z = w->zeros; m.s = w->scales; }
 
 int g_ao_mute = 0;    // profiling build: q4_set_gemv_early(9, n): the attention blocks of the next n launches do not publish
@@ -52,6 +69,15 @@ void attention_set_kv_price(const unsigned* sync, double ticks_per_pos) {
 double attention_get_kv_price(const unsigned* sync) { auto it = kv_price().find(sync); return it == kv_price().end() ? 0.0 : it->second; }
 
 struct AoShape { int att, slots_kind, slots, nsp; AttOprojLaunch launch; };
+
+int g_ao16 = 1;       // below the split-context bins, Llama-2-7B's shape: the launch on sixteen-wave blocks (profiling knob 20: 0 = the eight-wave launch)
+// the sixteen-wave launch takes this case: V-slice forms, 128-wide heads, K = dim = 4096, four units per head, and its waiting blocks (dim / 16) leave a slot
+static bool ao16_takes(const AoShape& s, int dim, int head_size, int n_heads) {
+    if (!g_ao16 || (s.att != 5 && s.att != 6) || s.slots_kind != 0 || head_size != 128 || dim != 4096 || s.nsp != 4 || n_heads * 4 * 2 > 65535) return false;
+    static int per_cu = -1;
+    if (per_cu < 0) { int n = 0; per_cu = launch_attention_oproj16(5, dim3(1), AttOprojArgs{}, &n) == Q4_OK ? n : 0; }
+    return !g_ao_guard || (long long)per_cu * stream_cu_count() >= dim / 16 + 1;
+}
 
 // Which form the launch would use for this geometry and bin, or att = -1 when there is none (the caller then runs the
 // stand-alone launches): head 64 / 128 / 256, multi-head or grouped-query, K = dim in <= 2 k-slots, 3 with a shared half slot,
@@ -153,6 +179,10 @@ int launch_attention_oproj(q4_half* x, q4_half* xb, const q4_half* q, const q4_h
     a.dbg = g_dbg;
     if (g_ao_mute > 0) { a.mute = 1; g_ao_mute--; }
 #endif
+    if (ao16_takes(s, dim, head_size, n_heads)) {
+        a.no = dim / 16;
+        return launch_attention_oproj16(s.att, dim3(a.natt + a.no), a, nullptr);
+    }
     const size_t smem = ao_smem(s, head_size, seq_len_bin);
     if (smem > AO_LDS_MAX) return Q4_ERR_UNSUPPORTED_SIZE;
     return s.launch(s.slots_kind, s.att, dim3(a.natt + a.no), dim3(LA_WAVES * 64), smem, a, nullptr);

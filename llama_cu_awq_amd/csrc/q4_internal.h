@@ -101,6 +101,7 @@ extern int g_att_split_min;
 extern int g_ao_guard;
 extern int g_ao_vslice;
 extern int g_ao_hold_pct;
+extern int g_ao16;
 extern int g_multi_steps;
 // Which form of the int4 GEMV launches run. The shipped library only ever holds GEMV_PRODUCT; the profiling library's knob 11
 // (q4_set_gemv_early(11, form)) sets the others for A/B runs and for the bit-equality cases of tests/prof_cases.py.

@@ -290,6 +290,7 @@ void q4_set_gemv_early(int kind, int slots) {
     if (kind == 10) g_ao_vslice = slots;    // 0: one attention block per head below the split-context bins, 1: one per 64-byte V slice
     if (kind == 15) g_ao_hold_pct = slots;  // split-context bins: the o-proj role's weight requests held back this share of the K / V stream's estimated duration
     if (kind == 11) g_gemv_form = slots;    // a GemvForm (q4_internal.h): 0 = the product's choices, -1 = wave-owned kernels only, 1..6 loader / consumer engine, 8..19 strips settings
+    if (kind == 20) g_ao16 = slots;         // attention -> o-proj below the split-context bins: 1 sixteen-wave blocks (layer_attn.h), 0 eight-wave
     if (kind == 16) g_fp_pre = slots;       // FFN pair launch (gemv_ffn_pair.h): down pieces requested in front of a wave's first gather pass
     if (kind == 17) g_fp_mute = slots;
     if (kind == 18) g_fp_nt = slots;      // ... the blocks of the next `slots` launches do not publish (a real time-out)
