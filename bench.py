@@ -300,7 +300,7 @@ def main():
                 tj = tj_all.get("0", tj_all)
                 # measured HBM traffic / algorithmic bytes of the other launches of the token (same PMC passes, per kernel)
                 prefixes = {"qkv_rmsnorm_rope_q4": "gemv_q4_kernel<1,", "gemv_q4_hidden_to_dim_accum": ("gemv_q4_kernel<0,", "down_strip_kernel<"),
-                            "attention+oproj_accum (one launch, fusion level 3)": "attention_oproj_kernel<", "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
+                            "attention+oproj_accum (one launch, fusion level 3)": ("attention_oproj_kernel<", "attention_oproj16_kernel<"), "final_rmsnorm+classifier_f16": ("gemv_f16_kernel<", "cls_strip_kernel<"),
                             kb[dom_id][0]: ("ffn_pair_kernel<true, false, true",) if three else ("ffn_pair_kernel<",) if pair else ("gemv_q4_kernel<2,", "ffn_strip_kernel<", "ffn_strip_pair_kernel<")}
                 if three:
                     prefixes.pop("qkv_rmsnorm_rope_q4", None)

@@ -130,8 +130,15 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
 constexpr int LA16_WAVES = 16;
 constexpr size_t LA16_LDS = 16 * 1024;     // the attention role's scratch (32 + 16 x 128 + 256 floats) or the o-proj role's staged vector (8.5 KiB)
 template <int ATT>
-__global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(const AttOprojArgs a) {
+__global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsigned* const lead_sync, const int* const lead_pos, const q4_half* const lead_q, const q4_half* const lead_k,
+                                                                          const q4_half* const lead_v, const uint32_t* const lead_w, const uint32_t* const lead_z, const q4_half* const lead_s,
+                                                                          const AttOprojArgs a0) {
     static_assert(ATT == 5 || ATT == 6, "V-slice forms");
+    // (the eight pointers a block needs first lead the argument list: preloaded into SGPRs with the wave, see attention_oproj_kernel)
+    AttOprojArgs a = a0;
+    a.sync = lead_sync;
+    a.att.pPos = lead_pos; a.att.q = lead_q; a.att.key_cache = lead_k; a.att.value_cache = lead_v;
+    a.oproj.m[0].w = lead_w; a.oproj.m[0].z = lead_z; a.oproj.m[0].s = lead_s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,6 +177,9 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(cons
         SC[s] = __builtin_amdgcn_raw_buffer_load_b16(rs, (jj >> 2) * 2u, n * (unsigned)o.sh * 2u, Q4_ZS_AUX);
         W[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, jj * 16u, n * (unsigned)o.pw4 * 16u, Q4_W_AUX);
     }
+    // the residual too (nobody else writes x in this launch): read at the end it is one more dependent round trip in the launch's tail
+    uint16_t resid = 0;
+    if (o.accum && (int)n < o.N) resid = o.out[0][n];
     __builtin_amdgcn_sched_barrier(0);
     const unsigned tag = ee[1], dead = ee[0];
     unsigned* const error = sync_words + SYNC_ERROR;
@@ -230,7 +240,7 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(cons
     if (lane == 0 && (int)n < o.N) {
         q4_half* out = o.out[0];
         float r = tot;
-        if (o.accum) r += h2f(out[n]);                            // gpu_kernels.h:229-230
+        if (o.accum) r += h2f(resid);                             // gpu_kernels.h:229-230
         out[n] = f2h(r);                                          // :231
     }
 }

@@ -17,7 +17,7 @@ int launch_attention_oproj16(int att, dim3 grid, const AttOprojArgs& a, int* max
             *max_blocks_per_cu = n;
             return Q4_OK;
         }
-        Q4_LAUNCH(kernel, grid, dim3(LA16_WAVES * 64), LA16_LDS, a);
+        Q4_LAUNCH(kernel, grid, dim3(LA16_WAVES * 64), LA16_LDS, a.sync, a.att.pPos, a.att.q, a.att.key_cache, a.att.value_cache, a.oproj.m[0].w, a.oproj.m[0].z, a.oproj.m[0].s, a);
         Q4_LAUNCH_CHECK();
         return Q4_OK;
     };

@@ -74,14 +74,14 @@ def algorithmic(kernel, model, ntok):
         return qweight_bytes(h, d) + h * 2 + 2 * d * 2
     if kernel.startswith("gemv_f16_kernel") or kernel.startswith("cls_strip_kernel"):
         return v * d * 2 + d * 2 + v * 2
-    if kernel.startswith("attention_oproj_kernel"):
+    if kernel.startswith("attention_oproj_kernel") or kernel.startswith("attention_oproj16_kernel"):      # (16: the sixteen-wave launch of forms 5 / 6)
         # o-proj QWeight + residual in / out + q + attention output + K and V rows of the context, averaged over the context
         # lengths this form serves in a -n ntok run launched with the graph path's BINS (q4_set_use_graphs(2): tools/prof_decode.py,
         # bench.py --no-graphs; round 5 -- up to round 4 the eager run passed the exact context length and form 1 served 257..511).
         # form = third template argument (layer_attn.hip, ao_shape): 5 = V-slice blocks, bin 128; 6 = V-slice blocks, bin 256
         # (positions 129..256); 4 = 64-position chunks, bin 512 (257..512); 2 = 128-position chunks, bin 1024; 3 = 256-position chunks
         # above; 0 / 1 = one block per head (V-slice form switched off; not what the product runs)
-        m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel)
+        m = re.match(r"attention_oproj_kernel<\d+, \w+, (\d)", kernel) or re.match(r"attention_oproj16_kernel<(\d)", kernel)
         form = int(m.group(1)) if m else -1
         ranges = {0: (1, 128), 5: (1, 128), 1: (129, 256), 6: (129, 256), 4: (257, 512), 2: (513, 1024), 3: (1025, 2048)}
         if form not in ranges:
