@@ -22,7 +22,8 @@ res = {v: [] for v in vals}
 for rep in range(3):
     for v in vals:
         L.q4_set_gemv_early(knob, v)
-        assert np.array_equal(t.generate_ids(prompt, ntok)[0], want), v
+        same = np.array_equal(t.generate_ids(prompt, ntok)[0], want)
+        assert same or os.environ.get("RINGS_MAY_DIFFER"), v      # (a knob that changes an fp32 summation order: set RINGS_MAY_DIFFER=1)
         res[v].append(max(t.generate_ids(prompt, ntok)[1] for _ in range(3)))
 for v in vals:
     print("%s -n %d level %d knob %d = %d: %s  median %.1f tokens/s" % (model, ntok, fusion, knob, v, " ".join("%.1f" % x for x in res[v]), float(np.median(res[v]))))
