@@ -128,8 +128,10 @@ __global__ void __launch_bounds__(LA_WAVES * 64) attention_oproj_kernel(unsigned
 // role multiplies ONE column per wave (dim / 16 blocks): reduce4_q4(c, 0, 0, 0) is row 0 of the two-column form's reduction, bit for bit. Same protocol.
 // ATT 5 / 6 as above (bins 128 / 256).
 constexpr int LA16_WAVES = 16;
-constexpr size_t LA16_LDS = 16 * 1024;     // the attention role's scratch (32 + 16 x 128 + 256 floats) or the o-proj role's staged vector (8.5 KiB)
-template <int ATT>
+constexpr size_t LA16_LDS = 16 * 1024;     // the attention role's scratch (32 + 16 x 128 + 256 floats) or the o-proj role's staged vector (8.5 / 12.75 KiB)
+// K5120: K = dim = 5120 (Llama-2-13B): two whole k-slots and the shared half slot of gemv_q4.h -- an even column's half-slot terms in lanes 0 .. 31, an odd
+// column's in lanes 32 .. 63, added (not fused) like there, so the reduction sees what the four-column form's sees
+template <int ATT, bool K5120 = false>
 __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsigned* const lead_sync, const int* const lead_pos, const q4_half* const lead_q, const q4_half* const lead_k,
                                                                           const q4_half* const lead_v, const uint32_t* const lead_w, const uint32_t* const lead_z, const q4_half* const lead_s,
                                                                           const AttOprojArgs a0) {
@@ -167,12 +169,13 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsi
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].w, 0, o.N * o.pw4 * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].z, 0, o.N * o.pzh * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o.m[0].s, 0, o.N * o.sh * 2, 0x00020000);
-    u32x4 W[2];
-    unsigned ZW[2];
-    uint16_t SC[2];
+    constexpr int NS = K5120 ? 3 : 2;                // k-slots (the last one of K = 5120 is the half slot: units 128 .. 159)
+    u32x4 W[NS];
+    unsigned ZW[NS];
+    uint16_t SC[NS];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const unsigned jj = 64u * (unsigned)s + lane;
+    for (int s = 0; s < NS; s++) {
+        const unsigned jj = K5120 && s == 2 ? 128u + (lane & 31u) : 64u * (unsigned)s + lane;
         ZW[s] = __builtin_amdgcn_raw_buffer_load_b32(rz, (jj >> 5) * 4u, n * (unsigned)o.pzh * 4u, Q4_ZS_AUX);
         SC[s] = __builtin_amdgcn_raw_buffer_load_b16(rs, (jj >> 2) * 2u, n * (unsigned)o.sh * 2u, Q4_ZS_AUX);
         W[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, jj * 16u, n * (unsigned)o.pw4 * 16u, Q4_W_AUX);
@@ -190,9 +193,9 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsi
         if (i >= POLL_LIMIT) __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    u32x4* xs = reinterpret_cast<u32x4*>(smem);                    // [2][4][64] x 16 B permuted x
-    float* sx = reinterpret_cast<float*>(smem + 2 * 4096);        // [2][64] -(sum of the 32 x) * 2^-20
-    if (tid < 512u) {                                             // one 8-half chunk per thread: K = 4096
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                    // [NS][4][64] x 16 B permuted x
+    float* sx = reinterpret_cast<float*>(smem + NS * 4096);       // [NS][64] -(sum of the 32 x) * 2^-20
+    if (tid < (K5120 ? 640u : 512u)) {                            // one 8-half chunk per thread: K = 4096 / 5120
         u32x4 xraw = {0u, 0u, 0u, 0u};
         bool ok = true;
         for (unsigned tries = 0;; tries++) {
@@ -217,11 +220,13 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsi
     __syncthreads();
     float c = 0.f;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
+        const bool hs = K5120 && s == 2;
+        const unsigned lu = hs ? (lane & 31u) : lane;
         u32x4 X[4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) X[d] = xs[((s * 4 + d) << 6) + lane];
-        const float corr = sx[s * 64 + lane];
+        for (int d = 0; d < 4; d++) X[d] = xs[((s * 4 + d) << 6) + lu];
+        const float corr = sx[s * 64 + lu];
         float acc_e = 0.f, acc_o = 0.f;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -231,10 +236,16 @@ __global__ void __launch_bounds__(LA16_WAVES * 64) attention_oproj16_kernel(unsi
             acc_e = __builtin_amdgcn_fdot2(as_h2(tt & 0x000F000Fu), as_h2(X[d][2]), acc_e, false);
             acc_o = __builtin_amdgcn_fdot2(as_h2(tt & 0x00F000F0u), as_h2(X[d][3]), acc_o, false);
         }
-        const float zf = (float)((ZW[s] >> (((lane >> 2) & 7u) * 4u)) & 0xFu);
+        const float zf = (float)((ZW[s] >> (((lu >> 2) & 7u) * 4u)) & 0xFu);
         float t = __builtin_fmaf(acc_e, 16.f, acc_o);
         t = __builtin_fmaf(zf, corr, t);
-        c = __builtin_fmaf(h2f(SC[s]), t, c);
+        if (hs) {                   // gemv_q4.h's shared half slot: lanes 0 .. 31 work for the pair's even column, lanes 32 .. 63 for the odd one
+            const float v = h2f(SC[s]) * t;
+            const bool mine = ((lane >> 5) & 1u) == (n & 1u);
+            c += mine ? v : 0.f;
+        } else {
+            c = __builtin_fmaf(h2f(SC[s]), t, c);
+        }
     }
     const float tot = reduce4_q4(c, 0.f, 0.f, 0.f) * 1048576.f;
     if (lane == 0 && (int)n < o.N) {

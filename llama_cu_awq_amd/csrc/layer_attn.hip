@@ -21,8 +21,9 @@ int launch_attention_oproj16(int att, dim3 grid, const AttOprojArgs& a, int* max
         Q4_LAUNCH_CHECK();
         return Q4_OK;
     };
-    if (att == 5) return go(attention_oproj16_kernel<5>);
-    if (att == 6) return go(attention_oproj16_kernel<6>);
+    const bool k5120 = a.oproj.K == 5120;
+    if (att == 5) return k5120 ? go(attention_oproj16_kernel<5, true>) : go(attention_oproj16_kernel<5, false>);
+    if (att == 6) return k5120 ? go(attention_oproj16_kernel<6, true>) : go(attention_oproj16_kernel<6, false>);
     return Q4_ERR_UNSUPPORTED_SIZE;
 }
 
@@ -70,10 +71,11 @@ double attention_get_kv_price(const unsigned* sync) { auto it = kv_price().find(
 
 struct AoShape { int att, slots_kind, slots, nsp; AttOprojLaunch launch; };
 
-int g_ao16 = 1;       // below the split-context bins, Llama-2-7B's shape: the launch on sixteen-wave blocks (profiling knob 20: 0 = the eight-wave launch)
+int g_ao16 = 3;       // below the split-context bins: the launch on sixteen-wave blocks at dim 4096 (bit 0) / dim 5120 (bit 1) (profiling knob 20: 0 = the eight-wave launch)
 // the sixteen-wave launch takes this case: V-slice forms, 128-wide heads, K = dim = 4096, four units per head, and its waiting blocks (dim / 16) leave a slot
 static bool ao16_takes(const AoShape& s, int dim, int head_size, int n_heads) {
-    if (!g_ao16 || (s.att != 5 && s.att != 6) || s.slots_kind != 0 || head_size != 128 || dim != 4096 || s.nsp != 4 || n_heads * 4 * 2 > 65535) return false;
+    const bool shape = (dim == 4096 && s.slots_kind == 0 && (g_ao16 & 1)) || (dim == 5120 && s.slots_kind == 1 && (g_ao16 & 2));    // K = dim in two k-slots, or two and the half slot
+    if (!shape || (s.att != 5 && s.att != 6) || head_size != 128 || s.nsp != 4 || n_heads % 8) return false;
     static int per_cu = -1;
     if (per_cu < 0) { int n = 0; per_cu = launch_attention_oproj16(5, dim3(1), AttOprojArgs{}, &n) == Q4_OK ? n : 0; }
     return !g_ao_guard || (long long)per_cu * stream_cu_count() >= dim / 16 + 1;
