@@ -647,15 +647,15 @@ __global__ void __launch_bounds__(STRIP_WAVES * 64) ffn_pair_kernel(const u32x4*
     auto issue_qkv = [&](const int r) {                 // request r = 0 .. 5 of this wave: column cw = 3 wave + r / 2, k-slot r % 2; with r = 0 also a piece of side data
         const unsigned cw = 3u * (unsigned)wave + (unsigned)(r >> 1), m = cw >> 4, n = n0q + (((cw >> 3) & 1u) ? hp3 : 0u) + (cw & 7u);
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)q3.m[m].w, 0, (int)(a.K * 2048), 0x00020000);   // dim columns of 2 KiB
-        dma_piece(P::DW + cw * 2048u + (unsigned)(r & 1) * 1024u, voff, rq, n * 2048u + (unsigned)(r & 1) * 1024u);
+        dma_piece_free(P::DW + cw * 2048u + (unsigned)(r & 1) * 1024u, voff, rq, n * 2048u + (unsigned)(r & 1) * 1024u);
         if (r == 0 && wave < 12) {                     // the six runs of eight columns: 512 B of scales (waves 0 .. 5), 128 B of zero words (6 .. 11)
             const unsigned run = wave < 6 ? (unsigned)wave : (unsigned)wave - 6u, ms = run >> 1, ns = n0q + ((run & 1u) ? hp3 : 0u);
             if (wave < 6) {
                 const __amdgpu_buffer_rsrc_t rs = rsrc_from(q3.m[ms].s, ns * 64u, (unsigned)a.K * 64u);
-                if (lane < 32u) dma_piece_default(P::QSIDE_S + run * 512u, voff, rs, 0u);
+                if (lane < 32u) dma_piece_default_free(P::QSIDE_S + run * 512u, voff, rs, 0u);
             } else {
                 const __amdgpu_buffer_rsrc_t rz = rsrc_from(q3.m[ms].z, ns * 16u, (unsigned)a.K * 16u);
-                if (lane < 8u) dma_piece_default(P::QSIDE_Z + run * 128u, voff, rz, 0u);
+                if (lane < 8u) dma_piece_default_free(P::QSIDE_Z + run * 128u, voff, rz, 0u);
             }
         }
     };

@@ -12,6 +12,15 @@ namespace q4 {
 __device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+// the same without the "memory" clobber: for requests into LDS that the code around them neither reads nor writes -- the compiler may then move ITS loads
+// (the LDS reads of a dot-product step) across the request instead of serialising every step behind it. (Volatile: the requests keep their order among
+// themselves and with the barriers.)
+__device__ __forceinline__ void dma_piece_free(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff));
+}
+__device__ __forceinline__ void dma_piece_default_free(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff));
+}
 __device__ __forceinline__ void dma_piece_default(unsigned lds_dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
